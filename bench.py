@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native bmSparse engine.
+
+metric (BASELINE.json): "SpMV effective GB/s + SpGEMM GFLOP/s on SuiteSparse; % HBM/MFMA roofline".
+The ONE JSON line carries the SpMV figure as `value` (configs[1]: bmSparse SpMV fp32 on webbase-1M, 1 GPU) and the
+SpGEMM figures (configs[2], configs[3]) in `spgemm`.
+
+A step = one SpMV sweep u = A*v over one resident matrix.  SuiteSparse files cannot be downloaded here; unless
+`--mtx-dir` holds webbase-1M.mtx the workload is the synthetic stand-in of SURVEY.md 8(d): R-MAT scale 20, edge factor
+2, identity added (1 048 576 rows, ~3.13 M nnz -- webbase-1M has 1 000 005 rows, 3 105 536 nnz).  The matrix in bmSparse
+form is ~70 MB and would sit in the 256 MiB Infinity Cache, so the timed loop rotates over enough device-resident copies
+(> 512 MiB in total) that every sweep streams from HBM; the cache-warm figure is reported beside it as
+`warm_ms_per_step`.  Inputs are resident in HBM before the timed region starts.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): every rank sweeps its own copies (fixed work per GPU,
+no data-path collective; weak scaling); value = bytes swept by all ranks / max-over-ranks time.  The row-panel-sharded
+SpGEMM with its RCCL allgatherv (configs[4]) is timed in the same run and reported under `spgemm_sharded`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "bmsparse-spgemm-spmv_amd"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a copy kernel reaches
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA spec
+FP32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mtx-dir", default=os.environ.get("BMSP_MTX_DIR", ""))
+    ap.add_argument("--scale", type=int, default=20, help="R-MAT scale of the synthetic SpMV workload")
+    ap.add_argument("--edge-factor", type=float, default=2.0)
+    ap.add_argument("--batched", type=int, default=-1, help="-1 auto, 0 / 1 force the SpMV variant")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-spgemm", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def csr_bytes(rows, nnz):
+    """CUSP's bytes-per-SpMV convention for int32/fp32 CSR (cusp/performance/spmv/bytes_per_spmv.h:31-39)."""
+    return 2 * 4 * rows + 4 * nnz + 2 * 4 * nnz + 2 * 4 * rows
+
+
+def bmsp_spmv_bytes(info, itemsize=4):
+    """algorithmic bytes of one bmSparse sweep (BASELINE.md 4 / SURVEY.md 8(d)), with the layout the kernel reads:
+    key+bitmap+offset per block (24 B), values, the uint32 dense block-row pointer, x once, y once."""
+    nbr = (info["num_rows"] + 7) // 8
+    return 24 * info["block_num"] + itemsize * info["nnz"] + 4 * (nbr + 1) + itemsize * info["num_cols"] + itemsize * info["num_rows"]
+
+
+def load_spmv_workload(args):
+    from pybmsp import gen
+    import numpy as np
+    path = os.path.join(args.mtx_dir, "webbase-1M.mtx") if args.mtx_dir else ""
+    if path and os.path.exists(path):
+        return {"name": "webbase-1M (SuiteSparse file)", "path": path}
+    n, _, r, c, v = gen.rmat(args.scale, args.edge_factor, seed=1)
+    return {"name": "rmat(scale=%d, edge_factor=%g)+I, stand-in for webbase-1M" % (args.scale, args.edge_factor),
+            "coo": (n, n, r, c, v)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # before the bmsp library: one HIP runtime for both (see pybmsp docstring)
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import numpy as np
+    import pybmsp as B
+    from pybmsp import gen
+    B.set_device(local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def sync():
+        B.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
+
+    # ---------------- SpMV workload, resident in HBM ----------------
+    wl = load_spmv_workload(args)
+    if "path" in wl:
+        first = B.BmSpMatrix.from_mtx(wl["path"])
+        mk = lambda: B.BmSpMatrix.from_mtx(wl["path"])
+    else:
+        n, _, r, c, v = wl["coo"]
+        first = B.BmSpMatrix.from_coo(n, n, r, c, v)
+        mk = lambda: B.BmSpMatrix.from_coo(n, n, r, c, v)
+    info = first.info()
+    alg_bytes = bmsp_spmv_bytes(info)
+    eff_bytes = csr_bytes(info["num_rows"], info["nnz"])
+    copies = max(2, int(np.ceil(512 * 2 ** 20 / alg_bytes)) + 1)
+    mats = [first] + [mk() for _ in range(copies - 1)]
+    x = B.DeviceArray.from_host(gen.spmv_x(info["num_cols"], "ones"))  # v = 1 (SPMV.cu:279-281)
+    ys = [B.DeviceArray(info["num_rows"], np.float32) for _ in range(copies)]
+    avg_blocks_per_row = info["block_num"] / max(1, (info["num_rows"] + 7) // 8)
+    batched = bool(args.batched) if args.batched >= 0 else avg_blocks_per_row >= 48
+
+    def step(i):
+        k = i % copies
+        B.spmv(mats[k], x, ys[k], batched=batched)
+
+    for i in range(args.warmup):
+        step(i)
+    sync(); barrier(); sync()
+    e0, e1 = B.Event(), B.Event()
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(args.steps):
+        step(i)
+    e1.record()
+    sync(); barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_ms(e1)
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ms_per_step = wall * 1e3 / args.steps
+    value = world * eff_bytes * args.steps / wall / 1e9  # every rank sweeps the same amount of its own data
+
+    # cache-warm sweep (one copy only), for information
+    for i in range(10):
+        B.spmv(mats[0], x, ys[0], batched=batched)
+    sync()
+    w0, w1 = B.Event(), B.Event()
+    w0.record()
+    for i in range(args.steps):
+        B.spmv(mats[0], x, ys[0], batched=batched)
+    w1.record()
+    warm_ms = w0.elapsed_ms(w1) / args.steps
+
+    kern_ms = dev_ms / args.steps  # HIP events on the launch stream, over the timed region
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "spmv_sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": round(kern_ms, 5)}
+
+    out = {"metric": "bmSparse SpMV fp32 effective GB/s (CSR-convention bytes / time); SpGEMM GFLOP/s under `spgemm`",
+           "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic" if "coo" in wl else "suitesparse",
+           "config": {"workload": "bmSparse SpMV fp32, " + wl["name"], "rows": info["num_rows"], "nnz": info["nnz"],
+                      "blocks": info["block_num"], "x": "ones", "variant": "batched" if batched else "default",
+                      "hbm_resident_copies_rotated": copies, "effective_bytes_per_spmv": eff_bytes},
+           "warm_ms_per_step": round(warm_ms, 5), "warm_effective_GBs": round(eff_bytes / (warm_ms * 1e-3) / 1e9, 1),
+           "roofline": roofline}
+
+    # ---------------- SpGEMM (configs[2], configs[3]) on rank 0 / single GPU ----------------
+    if not args.skip_spgemm and world == 1:
+        out["spgemm"] = bench_spgemm(B, gen, np, args)
+    if world > 1 and not args.skip_spgemm:
+        out["spgemm_sharded"] = bench_spgemm_sharded(B, gen, np, torch, dist, rank, world)
+
+    # ---------------- CPU baseline (cusp::multiply restatement) on rank 0, N = 1 only ----------------
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        out["cpu_baseline"] = cpu_baseline(wl, eff_bytes, args)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_spgemm(B, gen, np, args):
+    """A x A on the synthetic stand-ins of 2cubes_sphere (fp32, vector-ALU block-MAC) and cage12 (fp16, MFMA block-MAC)."""
+    res = []
+    cases = [("2cubes_sphere-like banded(101492, half_bw=8)", gen.banded(101492, 8), B.F32, 5, "2cubes_sphere.mtx"),
+             ("cage12-like rmat(scale=17, edge_factor=14.5)+I", gen.rmat(17, 14.5), B.F16, 4, "cage12.mtx")]
+    for name, coo, dtype, tc, fname in cases:
+        path = os.path.join(args.mtx_dir, fname) if args.mtx_dir else ""
+        if path and os.path.exists(path):
+            A = B.BmSpMatrix.from_mtx(path, False, dtype)
+            At = B.BmSpMatrix.from_mtx(path, True, dtype)
+            name = fname + " (SuiteSparse file)"
+        else:
+            n, _, r, c, v = coo
+            A = B.BmSpMatrix.from_coo(n, n, r, c, v, dtype=dtype)
+            At = B.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=dtype)
+        best = None
+        for it in range(4):  # first call warms the pool
+            Cm, st = B.spgemm(A, At, mode=B.SORT_AUTO, tc_version=tc)
+            if it and (best is None or st["t_us"][0] < best["t_us"][0]):
+                best = st
+            del Cm
+        info = A.info()
+        P = scalar_products(np, A)
+        t_total = best["t_us"][0] * 1e-6
+        t_mac = best["t_us"][7] * 1e-6
+        f_mac = 1024.0 * best["surviving_tasks"]
+        peak = MFMA_F16_PEAK_TFLOPS if dtype == B.F16 else FP32_PEAK_TFLOPS
+        res.append({"workload": "bmSparse SpGEMM A*A %s, %s" % ("fp16 MFMA block-MAC" if dtype == B.F16 else "fp32", name),
+                    "rows": info["num_rows"], "nnz": info["nnz"], "blocks": info["block_num"],
+                    "tasks": best["task_list_size"], "surviving_tasks": best["surviving_tasks"], "c_blocks": best["c_blocks"],
+                    "c_nnz": best["c_nnz"], "scalar_products": int(P), "total_ms": round(t_total * 1e3, 3),
+                    "gflops": round(2.0 * P / t_total / 1e9, 2),
+                    "stage_us": {k: round(best["t_us"][i], 1) for k, i in (("T_1", 1), ("T_2", 2), ("T_3", 3), ("T_4", 4), ("T_5", 5), ("T_6", 6), ("T_9", 9), ("T_7", 7))},
+                    "sort_path": "segmented" if best["sort_path"] else "global radix",
+                    "roofline": {"bound": "mfma" if dtype == B.F16 else "valu", "kernel": "block_mac", "achieved": round(f_mac / t_mac / 1e12, 3),
+                                 "peak": peak, "unit": "TFLOP/s", "frac": round(f_mac / t_mac / 1e12 / peak, 5), "traffic": None}})
+    return res
+
+
+def scalar_products(np, A):
+    """P = number of scalar products a_ik * b_kj of A*A = sum over stored a_ik of nnz(row k of A)."""
+    r, c, _ = A.to_coo()
+    rownnz = np.bincount(r, minlength=A.num_rows)
+    return int(rownnz[c].sum())
+
+
+def bench_spgemm_sharded(B, gen, np, torch, dist, rank, world):
+    """configs[4]: row-panel-sharded SpGEMM with an allgatherv of the C panels over RCCL.  Scale is reduced from 22 so
+    the default run stays within minutes (generation is host-side numpy); fixed total work -> strong scaling."""
+    from pybmsp import shard
+    scale = int(os.environ.get("BMSP_SHARD_SCALE", "18"))
+    n, _, r, c, v = gen.rmat(scale, 8)
+    A = B.BmSpMatrix.from_coo(n, n, r, c, v, dtype=B.F16)
+    Bt = B.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=B.F16)
+    best = None
+    for it in range(3):
+        B.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        Cm, stats = shard.spgemm_sharded(A, Bt, rank, world, dist, torch, tc_version=4)
+        B.synchronize(); dist.barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if it and (best is None or float(t.item()) < best[0]):
+            best = (float(t.item()), stats, Cm.info())
+        del Cm
+    P = scalar_products(np, A) if rank == 0 else 0
+    return {"workload": "row-panel-sharded SpGEMM fp16 MFMA, rmat(scale=%d, ef=8)+I" % scale, "scaling": "strong", "n_gpus": world,
+            "total_ms": round(best[0] * 1e3, 3), "gflops": round(2.0 * P / best[0] / 1e9, 2), "c_blocks": best[2]["block_num"],
+            "c_nnz": best[2]["nnz"], "allgatherv_bytes": best[1]["gather_bytes"], "allgatherv_ms": round(best[1]["gather_ms"], 3),
+            "panel_tasks": best[1]["tasks"]}
+
+
+def cpu_baseline(wl, eff_bytes, args):
+    """oracle (`port` of cusp::multiply, csr_spmv.h:56-73 + the OpenMP row-parallel variant) on this box's host cores,
+    on the same matrix and x; bounded to ~cpu-seconds of work."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import numpy as np
+    import oracle as O
+    from pybmsp import gen
+    if "path" in wl:
+        coo = O.mtx_read(wl["path"], strict=True)
+    else:
+        n, _, r, c, v = wl["coo"]
+        coo = O.Coo(n, n, r, c, v)
+    A = O.csr_from_coo(coo)
+    x = gen.spmv_x(A.num_cols, "ones")
+    th = O.max_threads()
+    res = {}
+    for name, t in (("omp", th), ("seq", 1)):
+        O.csr_spmv(A, x, t)
+        t0 = time.perf_counter()
+        O.csr_spmv(A, x, t)
+        one = max(1e-6, time.perf_counter() - t0)
+        iters = int(min(2000, max(10, (args.cpu_seconds / 2) / one)))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.csr_spmv(A, x, t)
+        dt = (time.perf_counter() - t0) / iters
+        res[name] = (eff_bytes / dt / 1e9, iters, dt)
+    return {"value": round(res["omp"][0], 2), "unit": "GB/s", "cores": th, "kind": "port",
+            "sample": "CSR SpMV (cusp::multiply restatement, OpenMP row-parallel) on the same matrix and x, %d iterations, %.2f ms each; "
+                      "single-thread: %.2f GB/s over %d iterations" % (res["omp"][1], res["omp"][2] * 1e3, res["seq"][0], res["seq"][1])}
+
+
+if __name__ == "__main__":
+    main()

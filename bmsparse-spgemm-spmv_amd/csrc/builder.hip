@@ -1,0 +1,411 @@
+// builder.hip -- MatrixMarket ingestion and the COO -> 8x8 bitmap-block (bmSparse) builder on the device.
+//
+// Reference behaviour: bmSpMatrix<T>::bmSpMatrix(path, transposed), src/bmSpMatrix.cu:111-219 -- host text
+// parse, comparator sort of (row,col,val) tuples by (block row, block col, intra-tile order), then
+// reduce_by_key passes for keys / offsets / bitmaps.  Here the comparator sort becomes ONE radix sort of a
+// packed integer key  (block_row | block_col | 6-bit tile position)  restricted to the bits the matrix uses,
+// and keys / offsets / bitmaps / duplicate-summed values come out of a single scan-fused pass.
+#include "matrix.h"
+#include "prims.hip.h"
+#include <algorithm>
+#include <cctype>
+#include <memory>
+#include <cerrno>
+#include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace bmsp {
+
+// ------------------------------------------------------------------------------------------------
+// MatrixMarket reader (host)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct MappedFile {
+    const char *p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    ~MappedFile()
+    {
+        if (p && n) munmap((void *)p, n);
+        if (fd >= 0) close(fd);
+    }
+};
+
+inline const char *skip_ws(const char *s, const char *e)
+{
+    while (s < e && (*s == ' ' || *s == '\t' || *s == '\r' || *s == '\n')) s++;
+    return s;
+}
+inline const char *skip_line(const char *s, const char *e)
+{
+    while (s < e && *s != '\n') s++;
+    return s < e ? s + 1 : e;
+}
+inline bool parse_i64(const char *&s, const char *e, long long &out)
+{
+    s = skip_ws(s, e);
+    if (s >= e) return false;
+    bool neg = false;
+    if (*s == '-' || *s == '+') { neg = *s == '-'; s++; }
+    if (s >= e || *s < '0' || *s > '9') return false;
+    long long v = 0;
+    while (s < e && *s >= '0' && *s <= '9') { v = v * 10 + (*s - '0'); s++; }
+    out = neg ? -v : v;
+    return true;
+}
+inline bool parse_f64(const char *&s, const char *e, double &out)
+{
+    s = skip_ws(s, e);
+    if (s >= e) return false;
+    char buf[64];
+    size_t k = 0;
+    while (s + k < e && k < sizeof(buf) - 1 && !(s[k] == ' ' || s[k] == '\t' || s[k] == '\r' || s[k] == '\n')) {
+        buf[k] = s[k];
+        k++;
+    }
+    buf[k] = 0;
+    char *endp = nullptr;
+    out = strtod(buf, &endp);
+    if (endp == buf) return false;
+    s += k;
+    return true;
+}
+}  // namespace
+
+void read_matrix_market(const std::string &path_in, HostCoo &out)
+{
+    std::string path = path_in;
+    struct stat sb;
+    if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        std::string alt = path + ".mtx";  // the reference's mains pass the name with and without the suffix
+        if (stat(alt.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode))
+            fail(BMSP_ERR_IO, "cannot open MatrixMarket file '%s' (also tried '%s')", path.c_str(), alt.c_str());
+        path = alt;
+    }
+    MappedFile mf;
+    mf.fd = open(path.c_str(), O_RDONLY);
+    if (mf.fd < 0) fail(BMSP_ERR_IO, "cannot open '%s': %s", path.c_str(), strerror(errno));
+    mf.n = (size_t)sb.st_size;
+    if (mf.n == 0) fail(BMSP_ERR_IO, "'%s' is empty", path.c_str());
+    void *mp = mmap(nullptr, mf.n, PROT_READ, MAP_PRIVATE, mf.fd, 0);
+    if (mp == MAP_FAILED) { mf.n = 0; fail(BMSP_ERR_IO, "mmap('%s') failed: %s", path.c_str(), strerror(errno)); }
+    mf.p = (const char *)mp;
+    const char *s = mf.p, *e = mf.p + mf.n;
+
+    // banner
+    const char *l0 = s;
+    s = skip_line(s, e);
+    std::string banner(l0, (size_t)(s - l0));
+    bool pattern = false, cplx = false;
+    int sym = 0;  // 0 general, 1 symmetric/hermitian, -1 skew-symmetric
+    if (banner.rfind("%%MatrixMarket", 0) == 0) {
+        char t1[64] = "", t2[64] = "", t3[64] = "", t4[64] = "";
+        sscanf(banner.c_str() + 14, "%63s %63s %63s %63s", t1, t2, t3, t4);
+        for (char *t : {t1, t2, t3, t4})
+            for (char *q = t; *q; q++) *q = (char)tolower(*q);
+        if (strcmp(t1, "matrix") != 0) fail(BMSP_ERR_IO, "'%s': not a MatrixMarket matrix", path.c_str());
+        if (strcmp(t2, "coordinate") != 0)
+            fail(BMSP_ERR_UNSUPPORTED, "'%s': only coordinate storage is supported (got '%s')", path.c_str(), t2);
+        pattern = !strcmp(t3, "pattern");
+        cplx = !strcmp(t3, "complex");
+        if (!pattern && !cplx && strcmp(t3, "real") && strcmp(t3, "integer"))
+            fail(BMSP_ERR_IO, "'%s': unknown MatrixMarket field '%s'", path.c_str(), t3);
+        if (!strcmp(t4, "general")) sym = 0;
+        else if (!strcmp(t4, "symmetric") || !strcmp(t4, "hermitian")) sym = 1;
+        else if (!strcmp(t4, "skew-symmetric")) sym = -1;
+        else fail(BMSP_ERR_IO, "'%s': unknown MatrixMarket symmetry '%s'", path.c_str(), t4);
+    } else {
+        // no banner: the reference still consumes the first line and mirrors when it mentions "symmetric"
+        sym = banner.find("symmetric") != std::string::npos ? 1 : 0;
+    }
+    // comment lines
+    for (;;) {
+        const char *t = skip_ws(s, e);
+        if (t < e && *t == '%') { s = skip_line(t, e); continue; }
+        s = t;
+        break;
+    }
+    long long nr, nc, nz;
+    if (!parse_i64(s, e, nr) || !parse_i64(s, e, nc) || !parse_i64(s, e, nz) || nr < 0 || nc < 0 || nz < 0)
+        fail(BMSP_ERR_IO, "'%s': bad size line", path.c_str());
+    if (nr > 0x7fffffffLL || nc > 0x7fffffffLL) fail(BMSP_ERR_LIMIT, "'%s': dimensions exceed int32", path.c_str());
+    out.num_rows = (int)nr;
+    out.num_cols = (int)nc;
+    size_t cap = (size_t)(sym ? 2 * nz : nz);
+    out.rows.clear(); out.cols.clear(); out.vals.clear();
+    out.rows.reserve(cap); out.cols.reserve(cap); out.vals.reserve(cap);
+    for (long long l = 0; l < nz; l++) {
+        long long r, c;
+        double v = 1.0, im;
+        if (!parse_i64(s, e, r) || !parse_i64(s, e, c))
+            fail(BMSP_ERR_IO, "'%s': unexpected end of file at entry %lld of %lld", path.c_str(), l, nz);
+        if (!pattern && !parse_f64(s, e, v)) fail(BMSP_ERR_IO, "'%s': missing value at entry %lld", path.c_str(), l);
+        if (cplx && !parse_f64(s, e, im)) fail(BMSP_ERR_IO, "'%s': missing imaginary part at entry %lld", path.c_str(), l);
+        if (r < 1 || c < 1 || r > nr || c > nc)
+            fail(BMSP_ERR_IO, "'%s': entry %lld has index (%lld,%lld) outside %lldx%lld", path.c_str(), l, r, c, nr, nc);
+        out.rows.push_back((int)(r - 1)); out.cols.push_back((int)(c - 1)); out.vals.push_back(v);
+        if (sym && r != c) {  // mirror off-diagonal entries (src/bmSpMatrix.cu:142-147)
+            out.rows.push_back((int)(c - 1)); out.cols.push_back((int)(r - 1)); out.vals.push_back(sym < 0 ? -v : v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device builder
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct MakeSortKey {
+    const int *rows, *cols;
+    uint64_t *keys;
+    uint32_t *perm;
+    int cbits;
+    int transposed;
+    __device__ void operator()(uint64_t i) const
+    {
+        uint32_t r = (uint32_t)rows[i], c = (uint32_t)cols[i];
+        // intra-tile position: coord_to_bmp (src/bmSpMatrix.cu:85-98)
+        uint32_t pos = transposed ? ((c & 7u) << 3) | (r & 7u) : ((r & 7u) << 3) | (c & 7u);
+        keys[i] = ((uint64_t)(r >> 3) << (cbits + 6)) | ((uint64_t)(c >> 3) << 6) | pos;
+        perm[i] = (uint32_t)i;
+    }
+};
+
+// packed head flags: high word = first element of a block, low word = first element of a coordinate
+struct HeadFlags {
+    const uint64_t *sk;
+    uint64_t n;
+    __device__ uint64_t operator()(uint64_t i) const
+    {
+        if (i >= n) return 0;
+        if (i == 0) return (1ull << 32) | 1ull;
+        uint64_t a = sk[i - 1], b = sk[i];
+        return ((uint64_t)((a >> 6) != (b >> 6)) << 32) | (uint64_t)(a != b);
+    }
+};
+
+struct CountOut {
+    uint64_t n;
+    uint64_t *totals;  // [0] = packed (blocks<<32 | elements)
+    __device__ void operator()(uint64_t i, uint64_t ex) const
+    {
+        if (i == n) totals[0] = ex;
+    }
+};
+
+template <typename T>
+struct ValCast;
+template <>
+struct ValCast<float> {
+    static __device__ float from(double d) { return (float)d; }
+};
+template <>
+struct ValCast<double> {
+    static __device__ double from(double d) { return d; }
+};
+template <>
+struct ValCast<_Float16> {
+    static __device__ _Float16 from(double d)
+    {
+        uint16_t b = f64_to_f16_bits(d);  // single rounding, like (half)double (src/bmSpMatrix.cu:141)
+        return __builtin_bit_cast(_Float16, b);
+    }
+};
+
+template <typename T>
+struct EmitBlocks {
+    const uint64_t *sk;
+    const uint32_t *perm;
+    const double *vals_in;
+    uint64_t n;
+    int cbits;
+    uint64_t *keys, *bmps, *offsets;
+    T *values;
+    __device__ void operator()(uint64_t i, uint64_t ex) const
+    {
+        uint32_t b = (uint32_t)(ex >> 32), el = (uint32_t)ex;
+        if (i == n) {
+            offsets[b] = el;  // terminal offset = nnz
+            return;
+        }
+        uint64_t k = sk[i];
+        bool ehead = i == 0 || sk[i - 1] != k;
+        if (!ehead) return;
+        // value of this coordinate: duplicates summed in input order in the matrix's own precision
+        T acc = ValCast<T>::from(vals_in[perm[i]]);
+        for (uint64_t j = i + 1; j < n && sk[j] == k; j++) acc = acc + ValCast<T>::from(vals_in[perm[j]]);
+        values[el] = acc;
+        bool bhead = i == 0 || (sk[i - 1] >> 6) != (k >> 6);
+        if (!bhead) return;
+        uint64_t blk = k >> 6;
+        uint64_t bmp = 0;
+        for (uint64_t j = i; j < n && (sk[j] >> 6) == blk; j++) bmp |= 1ull << (63 - (uint32_t)(sk[j] & 63u));
+        uint32_t bcol = (uint32_t)(blk & ((1ull << cbits) - 1ull));
+        uint32_t brow = (uint32_t)(blk >> cbits);
+        keys[b] = key_make(brow, bcol);  // coord_to_key (src/bmSpMatrix.cu:76-83)
+        bmps[b] = bmp;
+        offsets[b] = el;
+    }
+};
+
+template <typename T>
+void emit_blocks(const uint64_t *sk, const uint32_t *perm, const double *d_vals, uint64_t n, int cbits, bmsp_matrix_s *m,
+                 hipStream_t st)
+{
+    EmitBlocks<T> out{sk, perm, d_vals, n, cbits, m->keys, m->bmps, m->offsets, (T *)m->values};
+    device_exclusive_scan<uint64_t>(HeadFlags{sk, n}, out, n + 1, st);
+}
+
+struct RowPtrSearch {
+    const uint64_t *keys;
+    uint32_t nb;
+    uint32_t *rowptr;
+    __device__ void operator()(uint64_t r) const
+    {
+        // first block whose block-row is >= r
+        uint32_t lo = 0, hi = nb;
+        while (lo < hi) {
+            uint32_t mid = lo + ((hi - lo) >> 1);
+            if ((keys[mid] >> 32) < r) lo = mid + 1;
+            else hi = mid;
+        }
+        rowptr[r] = lo;
+    }
+};
+
+}  // namespace
+
+void free_matrix(bmsp_matrix_s *m)
+{
+    if (!m) return;
+    if (m->ownership == 1) {
+        pool_free(m->keys); pool_free(m->bmps); pool_free(m->offsets); pool_free(m->values);
+    }
+    pool_free(m->rowptr);
+    pool_free(m->spmv_chunks);
+    delete m;
+}
+
+void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st)
+{
+    if (m->rowptr) return;
+    int64_t nbr = m->num_block_rows();
+    if (m->block_num >= (1ll << 32)) fail(BMSP_ERR_LIMIT, "more than 2^32 blocks");
+    m->rowptr = (uint32_t *)pool_alloc(sizeof(uint32_t) * (size_t)(nbr + 1));
+    m->rowptr_rows = nbr;
+    device_for_each(RowPtrSearch{m->keys, (uint32_t)m->block_num, m->rowptr}, (uint64_t)nbr + 1, st);
+}
+
+bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, const int *d_rows, const int *d_cols,
+                                     const double *d_vals, int transposed, bmsp_dtype dtype, hipStream_t st)
+{
+    if (num_rows < 0 || num_cols < 0 || nnz < 0) fail(BMSP_ERR_INVALID, "negative dimension");
+    if (nnz >= (1ll << 32)) fail(BMSP_ERR_LIMIT, "nnz %lld exceeds the 32-bit element range", (long long)nnz);
+    std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> m(new bmsp_matrix_s(), free_matrix);
+    m->num_rows = num_rows; m->num_cols = num_cols; m->dtype = dtype; m->transposed = transposed ? 1 : 0;
+    uint64_t n = (uint64_t)nnz;
+    int rbits = ceil_log2_u64((uint64_t)m->num_block_rows());
+    int cbits = ceil_log2_u64((uint64_t)m->num_block_cols());
+
+    DevBuf<uint64_t> k0(n), k1(n);
+    DevBuf<uint32_t> p0(n), p1(n);
+    device_for_each(MakeSortKey{d_rows, d_cols, k0.p, p0.p, cbits, m->transposed}, n, st);
+    PingPong<uint64_t> kk{k0.p, k1.p};
+    PingPong<uint32_t> pp{p0.p, p1.p};
+    device_radix_sort_pairs<uint32_t>(kk, pp, n, 0, rbits + cbits + 6, st);
+
+    DevBuf<uint64_t> totals(1);
+    device_exclusive_scan<uint64_t>(HeadFlags{kk.cur, n}, CountOut{n, totals.p}, n + 1, st);
+    uint64_t packed = n ? read_back(totals.p, st) : 0;
+    m->block_num = (int64_t)(packed >> 32);
+    m->nnz = (int64_t)(packed & 0xffffffffull);
+    size_t nb = (size_t)m->block_num;
+    m->keys = (uint64_t *)pool_alloc(8 * (nb ? nb : 1));
+    m->bmps = (uint64_t *)pool_alloc(8 * (nb ? nb : 1));
+    m->offsets = (uint64_t *)pool_alloc(8 * (nb + 1));
+    m->values = pool_alloc(dtype_size(dtype) * (size_t)(m->nnz ? m->nnz : 1));
+    if (n == 0) {
+        BMSP_HIP(hipMemsetAsync(m->offsets, 0, 8, st));
+    } else if (dtype == BMSP_F32) emit_blocks<float>(kk.cur, pp.cur, d_vals, n, cbits, m.get(), st);
+    else if (dtype == BMSP_F16) emit_blocks<_Float16>(kk.cur, pp.cur, d_vals, n, cbits, m.get(), st);
+    else emit_blocks<double>(kk.cur, pp.cur, d_vals, n, cbits, m.get(), st);
+    ensure_rowptr(m.get(), st);
+    BMSP_HIP(hipStreamSynchronize(st));  // temporaries go back to the pool below
+    return m.release();
+}
+
+// ------------------------------------------------------------------------------------------------
+// bmSparse -> COO sorted by (row, col)   (generate_coo, src/bmSpMatrix.cu:320-363)
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+struct ExpandBlocks {
+    const uint64_t *keys, *bmps, *offsets;
+    const T *values;
+    int transposed;
+    uint64_t *rc;   // (row << 32) | col per stored value
+    double *vals;
+    __device__ void operator()(uint64_t b) const
+    {
+        uint64_t bmp = bmps[b], off = offsets[b];
+        uint32_t brow = key_row(keys[b]), bcol = key_col(keys[b]);
+        uint32_t k = 0;
+        while (bmp) {
+            int p = __clzll((long long)bmp);
+            bmp &= ~(1ull << (63 - p));
+            uint32_t hi = (uint32_t)p >> 3, lo = (uint32_t)p & 7u;
+            uint32_t r = brow * 8 + (transposed ? lo : hi), c = bcol * 8 + (transposed ? hi : lo);
+            rc[off + k] = ((uint64_t)r << 32) | c;
+            vals[off + k] = (double)values[off + k];
+            k++;
+        }
+    }
+};
+struct GatherD {
+    const double *in;
+    const uint32_t *perm;
+    double *out;
+    __device__ void operator()(uint64_t i) const { out[i] = in[perm[i]]; }
+};
+struct Iota32 {
+    uint32_t *p;
+    __device__ void operator()(uint64_t i) const { p[i] = (uint32_t)i; }
+};
+}  // namespace
+
+void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st)
+{
+    uint64_t n = (uint64_t)m->nnz;
+    if (n == 0) return;
+    DevBuf<uint64_t> k0(n), k1(n);
+    DevBuf<uint32_t> p0(n), p1(n);
+    DevBuf<double> v0(n), v1(n);
+    uint64_t nb = (uint64_t)m->block_num;
+    if (m->dtype == BMSP_F32)
+        device_for_each(ExpandBlocks<float>{m->keys, m->bmps, m->offsets, (const float *)m->values, m->transposed, k0.p, v0.p}, nb, st);
+    else if (m->dtype == BMSP_F16)
+        device_for_each(ExpandBlocks<_Float16>{m->keys, m->bmps, m->offsets, (const _Float16 *)m->values, m->transposed, k0.p, v0.p}, nb, st);
+    else
+        device_for_each(ExpandBlocks<double>{m->keys, m->bmps, m->offsets, (const double *)m->values, m->transposed, k0.p, v0.p}, nb, st);
+    device_for_each(Iota32{p0.p}, n, st);
+    PingPong<uint64_t> kk{k0.p, k1.p};
+    PingPong<uint32_t> pp{p0.p, p1.p};
+    int cb = ceil_log2_u64((uint64_t)m->num_cols), rb = ceil_log2_u64((uint64_t)m->num_rows);
+    // sort by column bits, then by row bits (stable LSD): row-major order
+    device_radix_sort_pairs<uint32_t>(kk, pp, n, 0, cb, st);
+    device_radix_sort_pairs<uint32_t>(kk, pp, n, 32, 32 + rb, st);
+    device_for_each(GatherD{v0.p, pp.cur, v1.p}, n, st);
+    std::vector<uint64_t> hk(n);
+    BMSP_HIP(hipMemcpyAsync(hk.data(), kk.cur, 8 * n, hipMemcpyDeviceToHost, st));
+    BMSP_HIP(hipMemcpyAsync(vals, v1.p, 8 * n, hipMemcpyDeviceToHost, st));
+    BMSP_HIP(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < n; i++) {
+        rows[i] = (int)(hk[i] >> 32);
+        cols[i] = (int)(hk[i] & 0xffffffffull);
+    }
+}
+
+}  // namespace bmsp

@@ -1,0 +1,67 @@
+// matrix.h -- the device-resident bmSparse container behind bmsp_matrix_t
+// (class bmSpMatrix<T>, reference include/bmSpMatrix.h:20-40).
+#ifndef BMSP_MATRIX_H_
+#define BMSP_MATRIX_H_
+
+#include "runtime.h"
+#include <vector>
+
+struct bmsp_matrix_s {
+    int num_rows = 0, num_cols = 0;
+    int64_t nnz = 0, block_num = 0;
+    bmsp_dtype dtype = BMSP_F32;
+    int transposed = 0;
+    // the four public arrays of the reference container (device memory)
+    uint64_t *keys = nullptr;     // block_num
+    uint64_t *bmps = nullptr;     // block_num
+    uint64_t *offsets = nullptr;  // block_num + 1 (last = nnz)
+    void *values = nullptr;       // nnz elements of dtype
+    int ownership = 1;            // 1: arrays belong to the pool / this handle, 2: borrowed
+    // derived, built lazily and cached (never part of the reference's public state)
+    uint32_t *rowptr = nullptr;   // dense block-row pointer, num_block_rows()+1 entries
+    int64_t rowptr_rows = 0;
+    // sweep plan of the SpMV (see spmv.hip): chunk descriptors
+    uint32_t *spmv_chunks = nullptr;
+    int64_t spmv_num_chunks = 0;
+    // a row-panel view points into its parent
+    int64_t view_block_begin = 0;
+
+    int64_t num_block_rows() const { return ((int64_t)num_rows + 7) / 8; }
+    int64_t num_block_cols() const { return ((int64_t)num_cols + 7) / 8; }
+};
+
+namespace bmsp {
+
+inline size_t dtype_size(bmsp_dtype t) { return t == BMSP_F16 ? 2 : (t == BMSP_F32 ? 4 : 8); }
+
+// host COO triples produced by the MatrixMarket parser
+struct HostCoo {
+    int num_rows = 0, num_cols = 0;
+    std::vector<int> rows, cols;
+    std::vector<double> vals;
+};
+
+// MatrixMarket coordinate reader (reference: src/bmSpMatrix.cu:111-161 ; CUSP reader semantics for
+// pattern / symmetric, cusp/io/detail/matrix_market.inl:171-196,245-292).
+void read_matrix_market(const std::string &path, HostCoo &out);
+
+// builder (reference: src/bmSpMatrix.cu:163-216) from COO triples resident on the device
+bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, const int *d_rows, const int *d_cols,
+                                     const double *d_vals, int transposed, bmsp_dtype dtype, hipStream_t st);
+
+void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st);
+void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st);
+void free_matrix(bmsp_matrix_s *m);
+
+void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st);
+void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int tc_version, int verbose, hipStream_t st,
+            bmsp_spgemm_stats *stats);
+template <typename T>
+struct PingPong;
+// stable sort of (key, task) pairs inside the runs of equal (key >> jbits): the SpGEMM's segmented path
+void segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, int ibits, hipStream_t st);
+void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const int *d_segs, int64_t num_segs,
+                 hipStream_t st);
+
+}  // namespace bmsp
+#endif

@@ -1,0 +1,291 @@
+// prims.hip.h -- hand-written device-wide primitives for gfx950 (wave64): exclusive scan with fused
+// input/output functors and a stable LSD radix sort of (uint64 key, payload) pairs.
+//
+// These replace the Thrust calls of the reference (scan / reduce_by_key / sort) and are the
+// building blocks of the builder (src/bmSpMatrix.cu:167-216) and of the SpGEMM symbolic stages
+// (src/bmSparse_SPGEMM.cu:839-1107).  All of them are HBM-bound integer passes: coalesced striped loads,
+// wave64 ballots/shuffles for ranking, LDS only for per-workgroup counters.
+#ifndef BMSP_PRIMS_HIP_H_
+#define BMSP_PRIMS_HIP_H_
+
+#include "runtime.h"
+#include "bmsp_bits.h"
+
+namespace bmsp {
+
+constexpr int kWave = 64;
+constexpr int kThreads = 256;          // 4 waves per workgroup
+constexpr int kItems = 16;             // elements per thread per tile
+constexpr int kTile = kThreads * kItems;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_sum(T v)
+{
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        T t = __shfl_up(v, d, kWave);
+        if (lane_id() >= d) v += t;
+    }
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+
+// exclusive scan of one value per thread across a 256-thread workgroup; `total` is the workgroup sum.
+// lds must hold 4 T's; two barriers inside, lds is reusable afterwards.
+template <typename T>
+__device__ __forceinline__ T block_exclusive_sum(T v, T *lds, T &total)
+{
+    T inc = wave_inclusive_sum(v);
+    if (lane_id() == kWave - 1) lds[wave_id()] = inc;
+    __syncthreads();
+    T w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
+    __syncthreads();
+    int w = wave_id();
+    T base = (w > 0 ? w0 : T(0)) + (w > 1 ? w1 : T(0)) + (w > 2 ? w2 : T(0));
+    total = w0 + w1 + w2 + w3;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan:  out(i, sum_{j<i} in(j))  for i in [0, n)
+// In : T operator()(uint64_t i) const ;  Out : void operator()(uint64_t i, T exclusive) const
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename In>
+__global__ __launch_bounds__(kThreads) void scan_tile_sums_kernel(In in, uint64_t n, T *tile_sums)
+{
+    __shared__ T lds[4];
+    uint64_t base = (uint64_t)blockIdx.x * kTile;
+    T local = 0;
+#pragma unroll 4
+    for (int k = 0; k < kItems; k++) {
+        uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
+        if (i < n) local += in(i);
+    }
+    local = wave_sum(local);
+    if (lane_id() == 0) lds[wave_id()] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+template <typename T, typename In, typename Out>
+__global__ __launch_bounds__(kThreads) void scan_tile_down_kernel(In in, Out out, uint64_t n, const T *tile_excl,
+                                                                  uint64_t tiles_per_block)
+{
+    __shared__ T lds[4];
+    // tile_excl == nullptr: a single workgroup walks all tiles with a running carry
+    uint64_t first_tile = (uint64_t)blockIdx.x * tiles_per_block;
+    T carry = tile_excl ? tile_excl[first_tile] : T(0);
+    for (uint64_t t = 0; t < tiles_per_block; t++) {
+        uint64_t base = (first_tile + t) * kTile;
+        if (base >= n) break;
+        for (int k = 0; k < kItems; k++) {
+            uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
+            T v = i < n ? in(i) : T(0);
+            T total;
+            T ex = block_exclusive_sum(v, lds, total);
+            if (i < n) out(i, carry + ex);
+            carry += total;
+        }
+    }
+}
+
+template <typename T>
+struct PtrIn {
+    const T *p;
+    __device__ T operator()(uint64_t i) const { return p[i]; }
+};
+template <typename T>
+struct PtrOut {
+    T *p;
+    __device__ void operator()(uint64_t i, T v) const { p[i] = v; }
+};
+
+template <typename T, typename In, typename Out>
+void device_exclusive_scan(In in, Out out, uint64_t n, hipStream_t st)
+{
+    if (n == 0) return;
+    uint64_t tiles = (n + kTile - 1) / kTile;
+    if (tiles <= 8) {
+        hipLaunchKernelGGL((scan_tile_down_kernel<T, In, Out>), dim3(1), dim3(kThreads), 0, st, in, out, n,
+                           (const T *)nullptr, tiles);
+        BMSP_CHECK_LAUNCH();
+        return;
+    }
+    DevBuf<T> sums(tiles);
+    hipLaunchKernelGGL((scan_tile_sums_kernel<T, In>), dim3((unsigned)tiles), dim3(kThreads), 0, st, in, n, sums.p);
+    BMSP_CHECK_LAUNCH();
+    device_exclusive_scan<T>(PtrIn<T>{sums.p}, PtrOut<T>{sums.p}, tiles, st);
+    hipLaunchKernelGGL((scan_tile_down_kernel<T, In, Out>), dim3((unsigned)tiles), dim3(kThreads), 0, st, in, out, n,
+                       (const T *)sums.p, (uint64_t)1);
+    BMSP_CHECK_LAUNCH();
+    // sums is returned to the pool here; the pool never hands memory back to the driver while kernels
+    // of this stream may still read it, and later users are ordered behind us on the same stream.
+}
+
+// ------------------------------------------------------------------------------------------------
+// stable LSD radix sort of (uint64 key, payload) pairs, 8 bits per pass, n < 2^32
+// ------------------------------------------------------------------------------------------------
+constexpr int kRadixBits = 8;
+constexpr int kRadixBins = 1 << kRadixBits;
+
+static __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint32_t n, int shift,
+                                                              uint32_t *__restrict__ hist, uint32_t num_tiles)
+{
+    __shared__ uint32_t h[kRadixBins];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t base = (uint64_t)blockIdx.x * kTile;
+#pragma unroll 4
+    for (int k = 0; k < kItems; k++) {
+        uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (kRadixBins - 1)], 1u);
+    }
+    __syncthreads();
+    hist[(uint64_t)threadIdx.x * num_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// Each wave owns a contiguous 1024-key slice of the tile and ranks it 64 keys at a time: lanes holding the
+// same digit find each other with 8 ballots, the lowest of them bumps the wave's LDS counter for that digit,
+// and every peer takes (old count + its position among the peers).  Slices, rounds and lanes are all visited
+// in index order, so equal digits keep their input order (stable).
+template <typename P>
+__global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t *__restrict__ kin, const P *__restrict__ pin,
+                                                                 uint64_t *__restrict__ kout, P *__restrict__ pout, uint32_t n,
+                                                                 int shift, const uint32_t *__restrict__ hist_scanned,
+                                                                 uint32_t num_tiles)
+{
+    __shared__ uint32_t cnt[4][kRadixBins];
+    __shared__ uint32_t dst_base[4][kRadixBins];
+    for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const uint64_t slice = (uint64_t)blockIdx.x * kTile + (uint64_t)w * (kTile / 4);
+    uint64_t key[kItems];
+    uint32_t rnk[kItems];
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        uint64_t i = slice + (uint64_t)r * kWave + lane;
+        bool valid = i < n;
+        key[r] = valid ? kin[i] : ~0ull;
+        uint32_t d = (uint32_t)(key[r] >> shift) & (kRadixBins - 1);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; b++) {
+            bool bit = (d >> b) & 1u;
+            uint64_t m = __ballot(valid && bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t old = 0;
+        int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+        if (valid && lane == leader) old = atomicAdd(&cnt[w][d], (uint32_t)__popcll(peers));
+        old = __shfl(old, leader, kWave);
+        rnk[r] = old + (uint32_t)__popcll(peers & lt);
+    }
+    __syncthreads();
+    {
+        uint32_t d = threadIdx.x;
+        uint32_t g = hist_scanned[(uint64_t)d * num_tiles + blockIdx.x];
+#pragma unroll
+        for (int ww = 0; ww < 4; ww++) {
+            dst_base[ww][d] = g;
+            g += cnt[ww][d];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        uint64_t i = slice + (uint64_t)r * kWave + lane;
+        if (i < n) {
+            uint32_t d = (uint32_t)(key[r] >> shift) & (kRadixBins - 1);
+            uint32_t dst = dst_base[w][d] + rnk[r];
+            kout[dst] = key[r];
+            pout[dst] = pin[i];
+        }
+    }
+}
+
+template <typename T>
+struct PingPong {
+    T *cur;
+    T *alt;
+    void flip()
+    {
+        T *t = cur;
+        cur = alt;
+        alt = t;
+    }
+};
+
+// Sorts by key bits [begin_bit, end_bit).  On return keys.cur / vals.cur hold the sorted data (they may be the
+// buffers that were passed as .alt).
+template <typename P>
+void device_radix_sort_pairs(PingPong<uint64_t> &keys, PingPong<P> &vals, uint64_t n64, int begin_bit, int end_bit,
+                             hipStream_t st)
+{
+    if (n64 == 0 || end_bit <= begin_bit) return;
+    if (n64 >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "radix sort: %llu elements exceed the 32-bit position range",
+                                  (unsigned long long)n64);
+    uint32_t n = (uint32_t)n64;
+    uint32_t tiles = (uint32_t)((n64 + kTile - 1) / kTile);
+    DevBuf<uint32_t> hist((size_t)kRadixBins * tiles);
+    for (int shift = begin_bit; shift < end_bit; shift += kRadixBits) {
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(kThreads), 0, st, keys.cur, n, shift, hist.p, tiles);
+        BMSP_CHECK_LAUNCH();
+        device_exclusive_scan<uint32_t>(PtrIn<uint32_t>{hist.p}, PtrOut<uint32_t>{hist.p}, (uint64_t)kRadixBins * tiles, st);
+        hipLaunchKernelGGL((radix_scatter_kernel<P>), dim3(tiles), dim3(kThreads), 0, st, keys.cur, vals.cur, keys.alt,
+                           vals.alt, n, shift, hist.p, tiles);
+        BMSP_CHECK_LAUNCH();
+        keys.flip();
+        vals.flip();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+inline dim3 grid_for(uint64_t n, int threads = kThreads)
+{
+    uint64_t g = (n + threads - 1) / threads;
+    if (g == 0) g = 1;
+    if (g > 0x7fffffffull) fail(BMSP_ERR_LIMIT, "grid too large");
+    return dim3((unsigned)g);
+}
+
+template <typename F>
+__global__ __launch_bounds__(kThreads) void for_each_kernel(F f, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f(i);
+}
+
+template <typename F>
+void device_for_each(F f, uint64_t n, hipStream_t st)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL((for_each_kernel<F>), grid_for(n), dim3(kThreads), 0, st, f, n);
+    BMSP_CHECK_LAUNCH();
+}
+
+template <typename T>
+T read_back(const T *dptr, hipStream_t st)
+{
+    T v;
+    BMSP_HIP(hipMemcpyAsync(&v, dptr, sizeof(T), hipMemcpyDeviceToHost, st));
+    BMSP_HIP(hipStreamSynchronize(st));
+    return v;
+}
+
+}  // namespace bmsp
+#endif

@@ -1,0 +1,109 @@
+// runtime.h -- error plumbing, pooled device memory and small RAII helpers shared by the HIP sources.
+#ifndef BMSP_RUNTIME_H_
+#define BMSP_RUNTIME_H_
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <stdexcept>
+#include <string>
+#include "../../include/bmsp.h"
+
+namespace bmsp {
+
+// thrown inside the library, translated to a bmsp_status at the C boundary
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string &msg) : std::runtime_error(msg), status(st) {}
+};
+
+[[noreturn]] void fail(int status, const char *fmt, ...);
+void set_last_error(const std::string &msg);
+
+#define BMSP_HIP(call)                                                                                     \
+    do {                                                                                                   \
+        hipError_t e__ = (call);                                                                           \
+        if (e__ != hipSuccess)                                                                             \
+            ::bmsp::fail(BMSP_ERR_HIP, "%s failed at %s:%d: %s", #call, __FILE__, __LINE__,                \
+                         hipGetErrorString(e__));                                                          \
+    } while (0)
+
+#define BMSP_CHECK_LAUNCH() BMSP_HIP(hipGetLastError())
+
+// Pooled device allocations.  hipMalloc/hipFree synchronise the device; the SpGEMM pipeline needs a dozen
+// temporaries per call, so freed blocks are kept (bucketed by rounded size) and handed out again.
+void *pool_alloc(size_t bytes);
+void pool_free(void *p);
+void pool_trim();
+bool pool_owns(void *p);
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept
+    {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count)
+    {
+        release();
+        n = count;
+        p = static_cast<T *>(pool_alloc((count ? count : 1) * sizeof(T)));
+    }
+    void release()
+    {
+        if (p) pool_free(p);
+        p = nullptr;
+        n = 0;
+    }
+    T *take()
+    {
+        T *q = p;
+        p = nullptr;
+        n = 0;
+        return q;
+    }
+    T *data() const { return p; }
+    size_t size() const { return n; }
+};
+
+inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
+
+// device-side timing of pipeline stages (hipEvent pairs on the operator's stream)
+struct StageTimer {
+    hipStream_t st;
+    hipEvent_t ev[2];
+    bool on;
+    StageTimer(hipStream_t s, bool enable) : st(s), on(enable)
+    {
+        if (on) { BMSP_HIP(hipEventCreate(&ev[0])); BMSP_HIP(hipEventCreate(&ev[1])); }
+    }
+    ~StageTimer()
+    {
+        if (on) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
+    }
+    void start() { if (on) BMSP_HIP(hipEventRecord(ev[0], st)); }
+    double stop_us()
+    {
+        if (!on) return 0.0;
+        BMSP_HIP(hipEventRecord(ev[1], st));
+        BMSP_HIP(hipEventSynchronize(ev[1]));
+        float ms = 0.f;
+        BMSP_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        return (double)ms * 1000.0;
+    }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace bmsp
+#endif

@@ -1,0 +1,112 @@
+// runtime.hip -- error state, pooled device memory.
+#include "runtime.h"
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace bmsp {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+const std::string &last_error() { return g_last_error; }
+
+[[noreturn]] void fail(int status, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(status, buf);
+}
+
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::map<size_t, std::vector<void *>> free_blocks;  // rounded size -> blocks
+    std::unordered_map<void *, size_t> live;            // every block we ever allocated -> rounded size
+    ~Pool() {}                                          // leave memory to process teardown (runtime may be gone)
+};
+Pool &pool()
+{
+    static Pool *p = new Pool();
+    return *p;
+}
+size_t round_size(size_t b)
+{
+    if (b < 512) return 512;
+    if (b <= (1u << 20)) return (b + 511) & ~size_t(511);
+    // above 1 MiB: round up to 1/8 of the leading power of two, so a block is reusable for similar sizes
+    size_t p2 = size_t(1) << (63 - __builtin_clzll((unsigned long long)b));
+    size_t step = p2 >> 3;
+    return (b + step - 1) / step * step;
+}
+}  // namespace
+
+void *pool_alloc(size_t bytes)
+{
+    size_t r = round_size(bytes);
+    Pool &P = pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.free_blocks.find(r);
+        if (it != P.free_blocks.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, r);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        pool_trim();
+        e = hipMalloc(&p, r);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            fail(BMSP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", r, hipGetErrorString(e));
+        }
+    }
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.live[p] = r;
+    return p;
+}
+
+void pool_free(void *p)
+{
+    if (!p) return;
+    Pool &P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) return;  // not ours (borrowed pointer): leave it alone
+    P.free_blocks[it->second].push_back(p);
+}
+
+bool pool_owns(void *p)
+{
+    Pool &P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    return P.live.find(p) != P.live.end();
+}
+
+void pool_trim()
+{
+    Pool &P = pool();
+    std::vector<void *> victims;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (auto &kv : P.free_blocks) {
+            for (void *p : kv.second) {
+                victims.push_back(p);
+                P.live.erase(p);
+            }
+            kv.second.clear();
+        }
+    }
+    if (!victims.empty()) (void)hipDeviceSynchronize();
+    for (void *p : victims) (void)hipFree(p);
+}
+
+}  // namespace bmsp

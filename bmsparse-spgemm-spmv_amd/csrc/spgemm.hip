@@ -1,0 +1,514 @@
+// spgemm.hip -- C = A * B on the bmSparse format: block-pair expansion, bitmap filter, sort of the pairs by
+// their (row, col) block key, segmented compress into C's layout, 8x8x8 block multiply-accumulate.
+//
+// Reference: bmSparse_mult<VI,VO>, src/bmSparse_SPGEMM.cu:827-1223 (stages T_1..T_9, T_7) and the block-MAC
+// kernels multiplyV15 (:204-291) / multiplyV11..V14 (:294-733).  Stage names below are the reference's.
+//
+// Differences by design (MI355X-first, same results):
+//   * tasks are 8 bytes (A block index, B block index as two uint32), not 16, and the unfiltered task list is
+//     never written to HBM: expansion and the bitmap filter (T_3 + T_4) are one load-balanced pass that is run
+//     twice (count, then write) instead of expand + remove_if;
+//   * the bitmap filter is two byte-OR reductions and an AND (tile_product_empty), not a 64-iteration loop;
+//   * the sort key is the packed (block_row, block_col) of C restricted to the bits in use; the sort is stable,
+//     so tasks of one C block stay in k-ascending order (the reference's order is unspecified above BORDER);
+//   * B's dense block-row pointer is cached on the matrix (T_1 is free after the first product).
+#include "matrix.h"
+#include "prims.hip.h"
+#include <memory>
+
+namespace bmsp {
+namespace {
+
+// ---- T_2 / T_3: fan-out of every A block = number of B blocks in block-row col(a) ------------------------
+struct FanOut {
+    const uint64_t *a_keys;
+    const uint32_t *b_rowptr;
+    uint64_t n_a;
+    uint32_t b_block_rows;
+    __device__ uint64_t operator()(uint64_t a) const
+    {
+        if (a >= n_a) return 0;
+        uint32_t col = key_col(a_keys[a]);
+        if (col >= b_block_rows) return 0;  // no matching block-row in B (reference indexes out of bounds here)
+        return (uint64_t)(b_rowptr[col + 1] - b_rowptr[col]);
+    }
+};
+
+// ---- T_3 + T_4: load-balanced expansion with the bitmap filter -------------------------------------------
+// A workgroup owns kTile consecutive candidate pairs.  The A blocks that generate them form a contiguous range
+// found by two binary searches; their first-candidate positions are staged in LDS and every candidate finds
+// its A block by a binary search there.
+constexpr int kSpanMax = kTile;  // staged first_pos entries
+
+struct ExpandArgs {
+    const uint64_t *first_pos;  // n_a + 1, exclusive scan of the fan-out
+    const uint64_t *a_keys, *a_bmps, *b_keys, *b_bmps;
+    const uint32_t *b_rowptr;
+    uint64_t n_a;
+    uint64_t total;  // candidates
+    int jbits;       // bits of C's block column in the sort key
+};
+
+__device__ __forceinline__ uint32_t upper_bound_u64(const uint64_t *p, uint32_t lo, uint32_t hi, uint64_t v)
+{  // first index in [lo,hi) with p[idx] > v
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (p[mid] <= v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kThreads) void expand_filter_kernel(ExpandArgs g, uint32_t *__restrict__ tile_counts,
+                                                                 const uint32_t *__restrict__ tile_base, uint64_t *__restrict__ out_keys,
+                                                                 uint64_t *__restrict__ out_tasks)
+{
+    __shared__ uint32_t rel[kSpanMax + 1];
+    __shared__ uint32_t range[2];
+    __shared__ uint32_t lds4[4];
+    const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
+    const uint64_t t1 = (t0 + (uint64_t)kTile < g.total) ? t0 + (uint64_t)kTile : g.total;
+    if (threadIdx.x == 0) range[0] = upper_bound_u64(g.first_pos, 0, (uint32_t)g.n_a + 1, t0) - 1;
+    if (threadIdx.x == 64) range[1] = upper_bound_u64(g.first_pos, 0, (uint32_t)g.n_a + 1, t1 - 1) - 1;
+    __syncthreads();
+    const uint32_t a_lo = range[0], a_hi = range[1];
+    const uint32_t span = a_hi - a_lo + 1;
+    const bool staged = span <= (uint32_t)kSpanMax;
+    if (staged) {
+        for (uint32_t k = threadIdx.x; k <= span; k += kThreads) {
+            uint64_t fp = g.first_pos[a_lo + k];
+            rel[k] = fp <= t0 ? 0u : (fp - t0 < (uint64_t)kTile ? (uint32_t)(fp - t0) : (uint32_t)kTile);
+        }
+    }
+    __syncthreads();
+    uint32_t carry = WRITE ? tile_base[blockIdx.x] : 0u;
+    uint32_t kept_total = 0;
+    for (int k = 0; k < kItems; k++) {
+        uint64_t t = t0 + (uint64_t)k * kThreads + threadIdx.x;
+        bool keep = false;
+        uint32_t a = 0, b = 0;
+        if (t < t1) {
+            uint32_t lt = (uint32_t)(t - t0);
+            if (staged) {
+                // last staged block whose first candidate is <= lt
+                uint32_t lo = 0, hi = span;
+                while (lo < hi) {
+                    uint32_t mid = lo + ((hi - lo + 1) >> 1);
+                    if (rel[mid] <= lt) lo = mid;
+                    else hi = mid - 1;
+                }
+                // (blocks with zero fan-out share a position with their successor; "last index <=" picks the
+                // owner, which is the last of such a run)
+                a = a_lo + lo;
+            } else {
+                a = upper_bound_u64(g.first_pos, a_lo, a_hi + 1, t) - 1;
+            }
+            uint64_t akey = g.a_keys[a];
+            b = g.b_rowptr[key_col(akey)] + (uint32_t)(t - g.first_pos[a]);
+            keep = !tile_product_empty(g.a_bmps[a], g.b_bmps[b]);  // multiplication_checker (:742-757)
+        }
+        if (WRITE) {
+            uint32_t total;
+            uint32_t ex = block_exclusive_sum<uint32_t>(keep ? 1u : 0u, lds4, total);
+            if (keep) {
+                uint64_t akey = g.a_keys[a];
+                uint64_t ck = ((uint64_t)key_row(akey) << g.jbits) | (uint64_t)key_col(g.b_keys[b]);
+                out_keys[carry + ex] = ck;
+                out_tasks[carry + ex] = ((uint64_t)a << 32) | (uint64_t)b;
+            }
+            carry += total;
+        } else {
+            kept_total += keep ? 1u : 0u;
+        }
+    }
+    if (!WRITE) {
+        kept_total = wave_sum(kept_total);
+        if (lane_id() == 0) lds4[wave_id()] = kept_total;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_counts[blockIdx.x] = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    }
+}
+
+struct CountIn {
+    const uint32_t *p;
+    uint64_t n;
+    __device__ uint32_t operator()(uint64_t i) const { return i < n ? p[i] : 0u; }
+};
+
+// ---- T_6: run-length encode the sorted C keys -----------------------------------------------------------------
+struct KeyHead {
+    const uint64_t *sk;
+    uint64_t n;
+    __device__ uint32_t operator()(uint64_t t) const
+    {
+        if (t >= n) return 0;
+        return (t == 0 || sk[t] != sk[t - 1]) ? 1u : 0u;
+    }
+};
+struct TotalOut32 {
+    uint64_t n;
+    uint32_t *total;
+    __device__ void operator()(uint64_t i, uint32_t ex) const
+    {
+        if (i == n) *total = ex;
+    }
+};
+struct EmitCBlocks {
+    const uint64_t *sk;
+    uint64_t n;
+    int jbits;
+    uint64_t *c_keys;
+    uint32_t *task_begin;
+    __device__ void operator()(uint64_t t, uint32_t ex) const
+    {
+        if (t == n) {
+            task_begin[ex] = (uint32_t)n;
+            return;
+        }
+        if (t == 0 || sk[t] != sk[t - 1]) {
+            uint64_t k = sk[t];
+            c_keys[ex] = key_make((uint32_t)(k >> jbits), (uint32_t)(k & ((1ull << jbits) - 1ull)));
+            task_begin[ex] = (uint32_t)t;
+        }
+    }
+};
+
+// ---- T_9: bitmap of every C block = OR of the boolean products of its tasks ---------------------------------
+struct CBitmaps {
+    const uint64_t *tasks;
+    const uint32_t *task_begin;
+    const uint64_t *a_bmps, *b_bmps;
+    uint64_t *c_bmps;
+    __device__ void operator()(uint64_t c) const
+    {
+        uint64_t acc = 0;
+        for (uint32_t t = task_begin[c]; t < task_begin[c + 1]; t++) {
+            uint64_t tk = tasks[t];
+            acc |= tile_product_bmp(a_bmps[tk >> 32], b_bmps[(uint32_t)tk]);  // bmp_calculator (:787-810)
+        }
+        c_bmps[c] = acc;
+    }
+};
+struct PopcIn {
+    const uint64_t *bmps;
+    uint64_t n;
+    __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)__popcll(bmps[i]) : 0ull; }
+};
+
+// ---- T_7: block multiply-accumulate, vector-ALU kernel with the reference's V15 numerics ---------------------
+// One wave per C block; lane l owns C(l/8, l%8).  Per task the wave expands the two tiles into LDS (lane l
+// fetches tile position l, zero when its bit is clear) and runs the 8-step inner product.  fp16 inputs: every
+// product is rounded to fp16 before the fp32 add, exactly as `__half * __half` does in multiplyV15 (:269-273).
+template <typename T>
+struct MacOps;
+template <>
+struct MacOps<float> {
+    using Out = float;
+    static __device__ __forceinline__ float step(float a, float b, float acc) { return __builtin_fmaf(a, b, acc); }
+};
+template <>
+struct MacOps<_Float16> {
+    using Out = float;
+    static __device__ __forceinline__ float step(_Float16 a, _Float16 b, float acc)
+    {
+        _Float16 p = a * b;  // rounded to fp16
+        return acc + (float)p;
+    }
+};
+template <>
+struct MacOps<double> {
+    using Out = double;
+    static __device__ __forceinline__ double step(double a, double b, double acc) { return __builtin_fma(a, b, acc); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void block_mac_valu_kernel(const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin,
+                                                                  const uint64_t *__restrict__ a_bmps, const uint64_t *__restrict__ a_offs,
+                                                                  const T *__restrict__ a_vals, const uint64_t *__restrict__ b_bmps,
+                                                                  const uint64_t *__restrict__ b_offs, const T *__restrict__ b_vals,
+                                                                  const uint64_t *__restrict__ c_bmps, const uint64_t *__restrict__ c_offs,
+                                                                  typename MacOps<T>::Out *__restrict__ c_vals, uint32_t c_size)
+{
+    using O = typename MacOps<T>::Out;
+    __shared__ T tile_a[4][64];
+    __shared__ T tile_b[4][64];
+    const int w = wave_id(), lane = lane_id();
+    const int i = lane >> 3, j = lane & 7;
+    for (uint32_t c = blockIdx.x * 4 + w; c < c_size; c += gridDim.x * 4) {
+        const uint32_t tb = task_begin[c], te = task_begin[c + 1];
+        O acc = 0;
+        for (uint32_t t = tb; t < te; t++) {
+            const uint64_t tk = tasks[t];
+            const uint32_t a = (uint32_t)(tk >> 32), b = (uint32_t)tk;
+            const uint64_t bmp_a = a_bmps[a], bmp_b = b_bmps[b];
+            T av = T(0), bv = T(0);
+            if (tile_has(bmp_a, lane)) av = a_vals[a_offs[a] + tile_rank(bmp_a, lane)];
+            if (tile_has(bmp_b, lane)) bv = b_vals[b_offs[b] + tile_rank(bmp_b, lane)];
+            __builtin_amdgcn_wave_barrier();
+            tile_a[w][lane] = av;  // A(i,k) at i*8+k
+            tile_b[w][lane] = bv;  // B stored column-major in the tile: B(k,j) at j*8+k
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc = MacOps<T>::step(tile_a[w][i * 8 + k], tile_b[w][j * 8 + k], acc);
+        }
+        const uint64_t bmp_c = c_bmps[c];
+        if (tile_has(bmp_c, lane)) c_vals[c_offs[c] + tile_rank(bmp_c, lane)] = acc;
+    }
+}
+
+// ---- T_7: block multiply-accumulate on the matrix cores (fp16 inputs, fp32 accumulate) ---------------------
+// v_mfma_f32_16x16x16_f16 computes a 16x16x16 product per wave.  Two C blocks are packed block-diagonally
+// (block 0 -> rows/cols 0-7, block 1 -> rows/cols 8-15) and two tasks of each block are packed along K
+// (k 0-7 and 8-15): four 8x8x8 block products per instruction (the packing idea of multiplyV14, :294-417).
+// Operand layout (gfx950): lane l supplies A[row = l&15][k = 4*(l>>4) .. +3] and B[k = 4*(l>>4) .. +3][col = l&15];
+// result lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3.  Every lane therefore needs FOUR CONSECUTIVE
+// k of one tile row (A, row-major tile) or of one tile column (B, column-major tile): one nibble of the bitmap
+// and up to four consecutive stored values -- straight from global memory, no LDS staging, no shuffles.
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ half4_t load_nibble(uint64_t bmp, const _Float16 *__restrict__ vals, int line, int khalf)
+{
+    // tile line `line` (row of A / column of B), k = 4*khalf .. 4*khalf+3  -> positions line*8 + 4*khalf + q
+    const int p0 = line * 8 + khalf * 4;
+    const uint32_t nib = (uint32_t)(bmp >> (60 - p0)) & 0xfu;  // bit 3 = k+0 ... bit 0 = k+3
+    half4_t r = {0, 0, 0, 0};
+    if (nib) {
+        const _Float16 *p = vals + tile_rank(bmp, p0);
+        if (nib & 8u) r[0] = *p++;
+        if (nib & 4u) r[1] = *p++;
+        if (nib & 2u) r[2] = *p++;
+        if (nib & 1u) r[3] = *p++;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_kernel(const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin,
+                                                                      const uint64_t *__restrict__ a_bmps, const uint64_t *__restrict__ a_offs,
+                                                                      const _Float16 *__restrict__ a_vals, const uint64_t *__restrict__ b_bmps,
+                                                                      const uint64_t *__restrict__ b_offs, const _Float16 *__restrict__ b_vals,
+                                                                      const uint64_t *__restrict__ c_bmps, const uint64_t *__restrict__ c_offs,
+                                                                      float *__restrict__ c_vals, uint32_t c_size)
+{
+    const int w = wave_id(), lane = lane_id();
+    const int line = lane & 7;          // tile row (A operand) / tile column (B operand)
+    const int which = (lane >> 3) & 1;  // which of the two packed C blocks this lane feeds (rows/cols 8-15 -> 1)
+    const int kq = lane >> 4;           // k quarter: 0,1 -> first task of the pair, 2,3 -> second task
+    const int slot = kq >> 1, khalf = kq & 1;
+    const uint32_t pairs = (c_size + 1) / 2;
+    for (uint32_t pr = blockIdx.x * 4 + w; pr < pairs; pr += gridDim.x * 4) {
+        const uint32_t c = pr * 2 + which;  // the C block this lane loads operands for
+        uint32_t tb = 0, te = 0;
+        if (c < c_size) { tb = task_begin[c]; te = task_begin[c + 1]; }
+        // both blocks advance two tasks per step; the wave runs until the longer list is exhausted
+        uint32_t len = te - tb;
+        uint32_t len_other = __shfl_xor(len, 8, kWave);
+        uint32_t steps = (max(len, len_other) + 1) / 2;
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t s = 0; s < steps; s++) {
+            const uint32_t t = tb + 2 * s + slot;
+            half4_t fa = {0, 0, 0, 0}, fb = {0, 0, 0, 0};
+            if (t < te) {
+                const uint64_t tk = tasks[t];
+                const uint32_t a = (uint32_t)(tk >> 32), b = (uint32_t)tk;
+                fa = load_nibble(a_bmps[a], a_vals + a_offs[a], line, khalf);
+                fb = load_nibble(b_bmps[b], b_vals + b_offs[b], line, khalf);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(fa, fb, acc, 0, 0, 0);
+        }
+        // result: lane holds D[4*(lane>>4)+r][lane&15]; block 0 lives in rows 0-7 x cols 0-7, block 1 in 8-15 x 8-15
+        const int col = lane & 15, rq = lane >> 4;
+        const int blk = col >> 3;
+        if ((rq >> 1) == blk) {
+            const uint32_t cc = pr * 2 + blk;
+            if (cc < c_size) {
+                const uint64_t bmp_c = c_bmps[cc];
+                const uint64_t off = c_offs[cc];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int p = ((rq & 1) * 4 + r) * 8 + (col & 7);
+                    if (tile_has(bmp_c, p)) c_vals[off + tile_rank(bmp_c, p)] = acc[r];
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+void launch_mac_valu(const uint64_t *tasks, const uint32_t *task_begin, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C,
+                     hipStream_t st)
+{
+    uint32_t cs = (uint32_t)C->block_num;
+    if (!cs) return;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)cs + 3) / 4, 256ull * 64);
+    hipLaunchKernelGGL((block_mac_valu_kernel<T>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin, A->bmps, A->offsets,
+                       (const T *)A->values, B->bmps, B->offsets, (const T *)B->values, C->bmps, C->offsets,
+                       (typename MacOps<T>::Out *)C->values, cs);
+    BMSP_CHECK_LAUNCH();
+}
+
+void print_stage(bool verbose, const char *name, double us)
+{
+    // the reference's VERBOSE lines (src/bmSparse_SPGEMM.cu:852 ..): "T_1: <n> μs "
+    if (verbose) printf("%s: %lld \xce\xbcs \n", name, (long long)(us + 0.5));
+}
+
+}  // namespace
+
+void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, int tc_version, int verbose, hipStream_t st,
+            bmsp_spgemm_stats *stats)
+{
+    if (!A || !B || !Cout) fail(BMSP_ERR_INVALID, "null argument");
+    if (A->transposed) fail(BMSP_ERR_INVALID, "A must be built with transposed=0");
+    if (!B->transposed) fail(BMSP_ERR_INVALID, "B must be built with transposed=1 (column-major tiles)");
+    if (A->num_cols != B->num_rows) fail(BMSP_ERR_INVALID, "shape mismatch: A is %dx%d, B is %dx%d", A->num_rows, A->num_cols, B->num_rows, B->num_cols);
+    if (A->dtype != B->dtype) fail(BMSP_ERR_INVALID, "A and B must have the same value type");
+    if (mode < 0 || mode > 2) fail(BMSP_ERR_INVALID, "sort mode must be 0, 1 or 2");
+    if (tc_version < 1 || tc_version > 5) fail(BMSP_ERR_INVALID, "tc_version must be 1..5");
+    const bool mfma = tc_version != 5 && A->dtype == BMSP_F16;
+
+    bmsp_spgemm_stats local{};
+    bmsp_spgemm_stats *S = stats ? stats : &local;
+    *S = bmsp_spgemm_stats{};
+    const bool timing = verbose || stats;
+    StageTimer whole(st, timing), tm(st, timing);
+    whole.start();
+
+    // T_1: blocks per block-row of B (cached dense pointer)
+    tm.start();
+    ensure_rowptr(B, st);
+    S->t_us[1] = tm.stop_us();
+    print_stage(verbose, "T_1", S->t_us[1]);
+
+    // T_2 + T_3 (first half): fan-out per A block and its exclusive scan
+    tm.start();
+    const uint64_t n_a = (uint64_t)A->block_num;
+    DevBuf<uint64_t> first_pos(n_a + 1);
+    device_exclusive_scan<uint64_t>(FanOut{A->keys, B->rowptr, n_a, (uint32_t)B->num_block_rows()}, PtrOut<uint64_t>{first_pos.p},
+                                    n_a + 1, st);
+    const uint64_t total = read_back(first_pos.p + n_a, st);
+    S->t_us[2] = tm.stop_us();
+    print_stage(verbose, "T_2", S->t_us[2]);
+    S->task_list_size = (int64_t)total;
+    if (verbose) printf("Task list size: %llu\n", (unsigned long long)total);
+    if (total >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "%llu candidate block pairs exceed the 32-bit task range; shard by row panel", (unsigned long long)total);
+
+    // T_3 + T_4: expansion fused with the bitmap filter
+    tm.start();
+    const int jbits = std::max(1, ceil_log2_u64((uint64_t)B->num_block_cols()));
+    const int ibits = std::max(1, ceil_log2_u64((uint64_t)A->num_block_rows()));
+    const uint32_t tiles = (uint32_t)((total + kTile - 1) / kTile);
+    ExpandArgs ea{first_pos.p, A->keys, A->bmps, B->keys, B->bmps, B->rowptr, n_a, total, jbits};
+    DevBuf<uint32_t> tile_counts((size_t)tiles + 1);
+    uint64_t n_tasks = 0;
+    DevBuf<uint64_t> k0, k1, v0, v1;
+    if (total) {
+        hipLaunchKernelGGL((expand_filter_kernel<false>), dim3(tiles), dim3(kThreads), 0, st, ea, tile_counts.p, (const uint32_t *)nullptr,
+                           (uint64_t *)nullptr, (uint64_t *)nullptr);
+        BMSP_CHECK_LAUNCH();
+        DevBuf<uint32_t> tile_base((size_t)tiles + 1);
+        device_exclusive_scan<uint32_t>(CountIn{tile_counts.p, tiles}, PtrOut<uint32_t>{tile_base.p}, (uint64_t)tiles + 1, st);
+        n_tasks = read_back(tile_base.p + tiles, st);
+        S->t_us[3] = tm.stop_us();
+        tm.start();
+        k0.alloc(n_tasks); k1.alloc(n_tasks); v0.alloc(n_tasks); v1.alloc(n_tasks);
+        hipLaunchKernelGGL((expand_filter_kernel<true>), dim3(tiles), dim3(kThreads), 0, st, ea, (uint32_t *)nullptr,
+                           (const uint32_t *)tile_base.p, k0.p, v0.p);
+        BMSP_CHECK_LAUNCH();
+        BMSP_HIP(hipStreamSynchronize(st));  // tile_base goes back to the pool
+        S->t_us[4] = tm.stop_us();
+    }
+    print_stage(verbose, "T_3", S->t_us[3]);
+    S->surviving_tasks = (int64_t)n_tasks;
+    S->bmp_reduction = (int64_t)(total - n_tasks);
+    if (verbose) printf("Bmp reduction: %lld\n", (long long)S->bmp_reduction);
+    print_stage(verbose, "T_4", S->t_us[4]);
+
+    // T_5: group the tasks by C key
+    tm.start();
+    PingPong<uint64_t> kk{k0.p, k1.p}, vv{v0.p, v1.p};
+    const bool segmented = mode == BMSP_SORT_SEGMENTED || (mode == BMSP_SORT_AUTO && n_tasks >= (uint64_t)BMSP_SORT_BORDER);
+    S->sort_path = segmented ? 1 : 0;
+    if (n_tasks) {
+        if (segmented) {
+            // tasks are already grouped by block-row of A (A's blocks are key-ordered): only the column bits
+            // need sorting inside each block-row segment
+            StageTimer ts(st, timing);
+            ts.start();
+            segsort_tasks_by_column(kk, vv, n_tasks, jbits, ibits, st);
+            S->t_us[8] = ts.stop_us();
+            if (verbose) print_stage(true, "Segmented sort", S->t_us[8]);
+        } else {
+            device_radix_sort_pairs<uint64_t>(kk, vv, n_tasks, 0, ibits + jbits, st);
+        }
+    }
+    S->t_us[5] = tm.stop_us();
+    print_stage(verbose, "T_5", S->t_us[5]);
+
+    // T_6: C's block keys and the task range of every C block
+    tm.start();
+    DevBuf<uint32_t> csize_d(1);
+    uint32_t c_size = 0;
+    if (n_tasks) {
+        device_exclusive_scan<uint32_t>(KeyHead{kk.cur, n_tasks}, TotalOut32{n_tasks, csize_d.p}, n_tasks + 1, st);
+        c_size = read_back(csize_d.p, st);
+    }
+    std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> C(new bmsp_matrix_s(), free_matrix);
+    C->num_rows = A->num_rows; C->num_cols = B->num_cols;  // :1171-1172
+    C->dtype = A->dtype == BMSP_F64 ? BMSP_F64 : BMSP_F32;  // OUTPUT_TYPE float (:51)
+    C->transposed = 0;
+    C->block_num = c_size;
+    C->keys = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
+    C->bmps = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
+    C->offsets = (uint64_t *)pool_alloc(8 * ((size_t)c_size + 1));
+    DevBuf<uint32_t> task_begin((size_t)c_size + 1);
+    if (n_tasks)
+        device_exclusive_scan<uint32_t>(KeyHead{kk.cur, n_tasks}, EmitCBlocks{kk.cur, n_tasks, jbits, C->keys, task_begin.p}, n_tasks + 1, st);
+    S->t_us[6] = tm.stop_us();
+    print_stage(verbose, "T_6", S->t_us[6]);
+
+    // T_9: C bitmaps, value offsets, nnz
+    tm.start();
+    uint64_t c_nnz = 0;
+    if (c_size) {
+        device_for_each(CBitmaps{vv.cur, task_begin.p, A->bmps, B->bmps, C->bmps}, c_size, st);
+        device_exclusive_scan<uint64_t>(PopcIn{C->bmps, c_size}, PtrOut<uint64_t>{C->offsets}, (uint64_t)c_size + 1, st);
+        c_nnz = read_back(C->offsets + c_size, st);
+    } else {
+        BMSP_HIP(hipMemsetAsync(C->offsets, 0, 8, st));
+    }
+    C->nnz = (int64_t)c_nnz;
+    C->values = pool_alloc(dtype_size(C->dtype) * (size_t)(c_nnz ? c_nnz : 1));
+    S->t_us[9] = tm.stop_us();
+    print_stage(verbose, "T_9", S->t_us[9]);
+
+    // T_7: block multiply-accumulate
+    tm.start();
+    if (c_size) {
+        if (mfma) {
+            uint32_t pairs = (c_size + 1) / 2;
+            uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)pairs + 3) / 4, 256ull * 64);
+            hipLaunchKernelGGL(block_mac_mfma_f16_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->bmps, A->offsets,
+                               (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
+                               (float *)C->values, c_size);
+            BMSP_CHECK_LAUNCH();
+            S->mac_kernel = tc_version;
+        } else {
+            if (A->dtype == BMSP_F32) launch_mac_valu<float>(vv.cur, task_begin.p, A, B, C.get(), st);
+            else if (A->dtype == BMSP_F16) launch_mac_valu<_Float16>(vv.cur, task_begin.p, A, B, C.get(), st);
+            else launch_mac_valu<double>(vv.cur, task_begin.p, A, B, C.get(), st);
+            S->mac_kernel = 5;
+        }
+    }
+    BMSP_HIP(hipStreamSynchronize(st));  // reference: cudaDeviceSynchronize (:1158)
+    S->t_us[7] = tm.stop_us();
+    print_stage(verbose, "T_7", S->t_us[7]);
+
+    S->c_blocks = c_size;
+    S->c_nnz = (int64_t)c_nnz;
+    S->t_us[0] = whole.stop_us();
+    *Cout = C.release();
+}
+
+}  // namespace bmsp

@@ -1,0 +1,92 @@
+"""Synthetic inputs of SURVEY.md 8(d): banded (FEM-like, dense-ish tiles) and R-MAT (graph-like, hyper-sparse tiles).
+
+Deterministic on every platform: all randomness comes from a counter-based splitmix64 evaluated with numpy
+uint64 arithmetic.  Matrices are returned as host COO triples (0-based int32 rows/cols, float64 values) with
+duplicates merged (summed) and entries sorted by (row, col).
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x):
+    """vectorised splitmix64 finaliser of the counter array x (uint64)."""
+    with np.errstate(over="ignore"):
+        z = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(counter):
+    """uniform doubles in [0,1) from a uint64 counter array."""
+    return (splitmix64(counter) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _merge(n_rows, n_cols, r, c, v):
+    key = r.astype(np.uint64) * np.uint64(n_cols) + c.astype(np.uint64)
+    uk, inv = np.unique(key, return_inverse=True)
+    vals = np.bincount(inv, weights=v, minlength=uk.size)
+    rows = (uk // np.uint64(n_cols)).astype(np.int32)
+    cols = (uk % np.uint64(n_cols)).astype(np.int32)
+    return rows, cols, vals
+
+
+def banded(n, half_bw, seed=1):
+    """entries at |i-j| <= half_bw, values U(-1,1)."""
+    i = np.repeat(np.arange(n, dtype=np.int64), 2 * half_bw + 1)
+    j = i + np.tile(np.arange(-half_bw, half_bw + 1, dtype=np.int64), n)
+    ok = (j >= 0) & (j < n)
+    i, j = i[ok], j[ok]
+    ctr = (np.uint64(seed) << np.uint64(40)) + (i.astype(np.uint64) * np.uint64(2 * half_bw + 1) + (j - i + half_bw).astype(np.uint64))
+    v = 2.0 * uniform01(ctr) - 1.0
+    return n, n, i.astype(np.int32), j.astype(np.int32), v
+
+
+def rmat(scale, edge_factor, a=0.57, b=0.19, c=0.19, seed=1, add_identity=True, chunk=1 << 22):
+    """R-MAT graph with 2**scale vertices and edge_factor * 2**scale generated edges; duplicates summed,
+    self-loops kept, identity added (so no block-row is empty), values U(0,1)."""
+    n = 1 << scale
+    m = int(edge_factor * n)
+    keys, vals = [], []
+    for e0 in range(0, m, chunk):
+        e = np.arange(e0, min(m, e0 + chunk), dtype=np.uint64)
+        r = np.zeros(e.size, dtype=np.uint64)
+        cc = np.zeros(e.size, dtype=np.uint64)
+        for lvl in range(scale):
+            u = uniform01((np.uint64(seed) << np.uint64(48)) + e * np.uint64(64) + np.uint64(lvl))
+            rb = (u >= a + b).astype(np.uint64)                      # quadrants c, d -> lower half
+            cb = (((u >= a) & (u < a + b)) | (u >= a + b + c)).astype(np.uint64)  # quadrants b, d -> right half
+            r = (r << np.uint64(1)) | rb
+            cc = (cc << np.uint64(1)) | cb
+        keys.append(r * np.uint64(n) + cc)
+        vals.append(uniform01((np.uint64(seed + 7) << np.uint64(48)) + e))
+    if add_identity:
+        d = np.arange(n, dtype=np.uint64)
+        keys.append(d * np.uint64(n) + d)
+        vals.append(np.ones(n))
+    key = np.concatenate(keys) if keys else np.zeros(0, np.uint64)
+    val = np.concatenate(vals) if vals else np.zeros(0)
+    uk, inv = np.unique(key, return_inverse=True)
+    v = np.bincount(inv, weights=val, minlength=uk.size)
+    return n, n, (uk // np.uint64(n)).astype(np.int32), (uk % np.uint64(n)).astype(np.int32), v
+
+
+def random_coo(n_rows, n_cols, nnz, seed=1, lo=-1.0, hi=1.0, integer=False):
+    """nnz random coordinates (duplicates merged), for ragged / empty-row edge cases."""
+    e = np.arange(nnz, dtype=np.uint64)
+    r = (splitmix64((np.uint64(seed) << np.uint64(40)) + e * np.uint64(3)) % np.uint64(max(1, n_rows))).astype(np.int64)
+    c = (splitmix64((np.uint64(seed) << np.uint64(40)) + e * np.uint64(3) + np.uint64(1)) % np.uint64(max(1, n_cols))).astype(np.int64)
+    v = lo + (hi - lo) * uniform01((np.uint64(seed) << np.uint64(40)) + e * np.uint64(3) + np.uint64(2))
+    if integer:
+        v = np.floor(v)
+        v[v == 0] = 1.0
+    rows, cols, vals = _merge(n_rows, n_cols, r, c, v)
+    return n_rows, n_cols, rows, cols, vals
+
+
+def spmv_x(n, kind="ones"):
+    """x vectors of SURVEY 8(d): all-ones (reference main, SPMV.cu:279-281) or (i % 21) - 10 (CUSP benchmark)."""
+    if kind == "ones":
+        return np.ones(n, dtype=np.float32)
+    return ((np.arange(n) % 21) - 10).astype(np.float32)

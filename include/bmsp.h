@@ -1,0 +1,204 @@
+/*
+ * bmsp.h -- C ABI of the MI355X-native bmSparse engine (libbmsp.so).
+ *
+ * This is the drop-in boundary.  The reference (GonzaBerger/bmSparse-SPGEMM-SPMV) has no FFI: its
+ * operators are C++ templates compiled into the two executables.  Every entry point below names the
+ * reference interface it replaces (paths relative to the reference repository root).  The C++ headers
+ * include/bmSpMatrix.h and include/CSRMatrix.h keep the reference's class / function names on top of
+ * this ABI, so a maintainer swaps the reference's nvcc translation units for `-lbmsp`.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `void *stream` is a hipStream_t (NULL = the null stream);
+ *   - "device pointer" means memory visible to the current HIP device (bmsp_malloc, hipMalloc, or a
+ *     PyTorch-ROCm tensor's data_ptr());
+ *   - every call returns BMSP_OK (0) or a negative bmsp_status; bmsp_last_error() gives the text for
+ *     the calling thread.  Nothing calls exit() (the reference exits on CUDA errors,
+ *     src/bmSparse_SPMV.cu:62-70);
+ *   - a missing / unreadable file is an error (the reference silently builds an empty matrix,
+ *     src/bmSpMatrix.cu:114-127);
+ *   - not thread-safe per matrix handle; distinct handles may be used from distinct threads.
+ */
+#ifndef BMSP_H_
+#define BMSP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMSP_BLOCK_WIDTH 8   /* include/bmSpMatrix.h:15 */
+#define BMSP_BLOCK_HEIGHT 8  /* include/bmSpMatrix.h:16 */
+
+typedef enum {
+    BMSP_OK = 0,
+    BMSP_ERR_INVALID = -1,   /* bad argument / shape mismatch */
+    BMSP_ERR_IO = -2,        /* file missing or malformed */
+    BMSP_ERR_HIP = -3,       /* a HIP runtime call failed */
+    BMSP_ERR_NOMEM = -4,
+    BMSP_ERR_UNSUPPORTED = -5,
+    BMSP_ERR_LIMIT = -6      /* a 32-bit internal limit would overflow */
+} bmsp_status;
+
+typedef enum { BMSP_F32 = 0, BMSP_F16 = 1, BMSP_F64 = 2 } bmsp_dtype;
+
+typedef struct bmsp_matrix_s *bmsp_matrix_t; /* replaces class bmSpMatrix<T>, include/bmSpMatrix.h:20-40 */
+typedef struct bmsp_csr_s *bmsp_csr_t;       /* replaces class CSRMatrix,     include/CSRMatrix.h:13-21 */
+
+const char *bmsp_last_error(void);
+const char *bmsp_version(void);
+
+/* ---- device plumbing (lets a plain-C/C++ host manage v and u the way the reference's main does
+ *      with cudaMalloc/cudaMemcpy, src/bmSparse_SPMV.cu:276-285,309) ---- */
+int bmsp_device_count(int *count);
+int bmsp_set_device(int device);
+int bmsp_malloc(void **dptr, size_t bytes);
+int bmsp_free(void *dptr);
+int bmsp_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int bmsp_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int bmsp_memcpy_d2d(void *dst, const void *src, size_t bytes);
+int bmsp_memset(void *dptr, int value, size_t bytes);
+int bmsp_synchronize(void);
+int bmsp_trim_pool(void); /* return cached device memory to the driver */
+/* device-side timing (hipEvent) on the stream the operators are launched on */
+int bmsp_event_create(void **event);
+int bmsp_event_record(void *event, void *stream);
+int bmsp_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+int bmsp_event_destroy(void *event);
+
+/* ---- container / builder ------------------------------------------------------------------- */
+
+/* bmSpMatrix<T>::bmSpMatrix(std::string path, bool transpose)  -- src/bmSpMatrix.cu:111-219.
+ * Parses a MatrixMarket coordinate file (real / integer / pattern; general / symmetric) on the host and
+ * builds keys/bmps/offsets/values on the device.  `transposed` lays tiles out column-major (the B operand
+ * of bmsp_spgemm, src/bmSparse_SPGEMM.cu:1262).  Accepts `path` with or without the ".mtx" suffix
+ * (the reference's two mains disagree, src/bmSparse_SPMV.cu:257,270). */
+int bmsp_matrix_from_mtx(const char *path, int transposed, bmsp_dtype dtype, bmsp_matrix_t *out);
+
+/* Same builder from host COO triples (0-based).  Values are double, cast to dtype with round-to-nearest-even
+ * exactly like the reference's `(valueType)data` (src/bmSpMatrix.cu:141).  Duplicate coordinates are summed
+ * (the reference corrupts its popcount addressing on duplicates, src/bmSpMatrix.cu:183-216). */
+int bmsp_matrix_from_coo(int num_rows, int num_cols, int64_t nnz, const int *rows, const int *cols,
+                         const double *vals, int transposed, bmsp_dtype dtype, bmsp_matrix_t *out);
+
+/* Same builder from COO triples already resident on the device (rows/cols int32, vals float64). */
+int bmsp_matrix_from_coo_device(int num_rows, int num_cols, int64_t nnz, const int *d_rows, const int *d_cols,
+                                const double *d_vals, int transposed, bmsp_dtype dtype, void *stream,
+                                bmsp_matrix_t *out);
+
+/* bmSpMatrix<T>::bmSpMatrix(int,int,int, keys&, bmps&, offsets&, values&)  -- src/bmSpMatrix.cu:30-43.
+ * ownership: 0 = copy the four device arrays; 1 = adopt them (they must come from bmsp_malloc; this is the
+ * reference's swap semantics); 2 = borrow (caller keeps them alive and frees them). */
+int bmsp_matrix_from_arrays(int num_rows, int num_cols, int64_t block_num, int64_t nnz, uint64_t *d_keys,
+                            uint64_t *d_bmps, uint64_t *d_offsets, void *d_values, bmsp_dtype dtype,
+                            int transposed, int ownership, bmsp_matrix_t *out);
+
+int bmsp_matrix_free(bmsp_matrix_t m);
+
+/* public members of bmSpMatrix<T>: num_rows, num_cols, nnz, block_num (include/bmSpMatrix.h:32) */
+int bmsp_matrix_info(bmsp_matrix_t m, int *num_rows, int *num_cols, int64_t *nnz, int64_t *block_num,
+                     bmsp_dtype *dtype, int *transposed);
+/* public members keys, bmps, offsets, values (include/bmSpMatrix.h:28-31) as device pointers.
+ * offsets carries block_num+1 entries (the last equals nnz); the reference holds block_num from the builder
+ * (src/bmSpMatrix.cu:194) and block_num+1 after a product (src/bmSparse_SPGEMM.cu:1087,1179). */
+int bmsp_matrix_arrays(bmsp_matrix_t m, uint64_t **d_keys, uint64_t **d_bmps, uint64_t **d_offsets,
+                       void **d_values);
+/* dense block-row pointer (num_block_rows+1 uint32 entries) the operators use; built once and cached
+ * (the reference rebuilds a compressed one on every call, src/bmSparse_SPMV.cu:199-206). */
+int bmsp_matrix_block_row_ptr(bmsp_matrix_t m, const uint32_t **d_rowptr, int64_t *num_block_rows);
+
+/* bmSpMatrix<T>::generate_coo()  -- src/bmSpMatrix.cu:320-363.  Expands to host COO sorted by (row,col);
+ * rows/cols/vals must hold nnz entries.  Unlike the reference it honours the transposed layout. */
+int bmsp_matrix_to_coo_host(bmsp_matrix_t m, int *rows, int *cols, double *vals);
+
+/* bmSpMatrix<T>::compare(coo)  -- src/bmSpMatrix.cu:381-432.  Mean relative error against a host COO
+ * comparand (entries of the comparand that are absent from m are skipped).  *missing counts entries of m
+ * that the comparand lacks (the reference would walk out of bounds). */
+int bmsp_matrix_compare(bmsp_matrix_t m, int64_t nnz, const int *rows, const int *cols, const double *vals,
+                        double *mean_rel_err, int64_t *missing);
+
+/* ---- operators ------------------------------------------------------------------------------ */
+
+/* variants of the SpMV sweep.  0 = reference's default path (`batched`=false, spmv_kernel
+ * src/bmSparse_SPMV.cu:153-189), 1 = the wavefront-reduce path `batched`=true was meant to select
+ * (spmv_kernel_new :84-150).  Both give the same u; they differ in the lane mapping. */
+#define BMSP_SPMV_DEFAULT 0
+#define BMSP_SPMV_BATCHED 1
+
+/* bmSparse_SpMV<VI,VO>(A, v, u, batched)  -- src/bmSparse_SPMV.cu:191-230.   u = A * v
+ * v: device, num_cols entries of A's dtype; u: device, num_rows entries (float for F32/F16, double for F64).
+ * Asynchronous on `stream`; A is not modified.  Rows of empty block-rows are written as 0. */
+int bmsp_spmv(bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *stream);
+
+/* per-stage figures of one product: the lines the reference prints when VERBOSE
+ * (src/bmSparse_SPGEMM.cu:849-1220) plus what the roofline needs. */
+typedef struct {
+    int64_t task_list_size;  /* candidate block pairs ("Task list size") */
+    int64_t bmp_reduction;   /* pairs dropped by the bitmap filter ("Bmp reduction") */
+    int64_t surviving_tasks;
+    int64_t c_blocks;        /* "C blocks" */
+    int64_t c_nnz;           /* "C nnz" (symbolic) */
+    double t_us[10];         /* device time per stage, microseconds: [1]=T_1 [2]=T_2 [3]=T_3 [4]=T_4 [5]=T_5
+                                [6]=T_6 [7]=T_7 [9]=T_9 ; [0]=whole call ("Toda F"); [8]=segmented sort only */
+    int sort_path;           /* 0 = global radix sort (reference: thrust::sort), 1 = segmented sort */
+    int mac_kernel;          /* which block-MAC kernel ran (see tc_version) */
+} bmsp_spgemm_stats;
+
+/* sort modes = the reference's `segmented` argument (src/bmSparse_SPGEMM.cu:963-1016):
+ * 0 = global sort below BMSP_SORT_BORDER surviving tasks, segmented sort above; 1 = always segmented;
+ * 2 = always global. */
+#define BMSP_SORT_AUTO 0
+#define BMSP_SORT_SEGMENTED 1
+#define BMSP_SORT_GLOBAL 2
+#define BMSP_SORT_BORDER 2730000 /* src/bmSparse_SPGEMM.cu:53 */
+
+/* bmSparse_mult<VI,VO>(A, B, C, mode, VERBOSE, tc_version)  -- src/bmSparse_SPGEMM.cu:827-1223.   C = A * B
+ * A: normal layout; B: built with transposed=1; same dtype.  *C receives a new fp32 (fp64 for F64 inputs)
+ * matrix in normal layout.  tc_version selects the block multiply-accumulate kernel like the reference's
+ * switch (:1132-1155): 5 = vector-ALU kernel with the reference's V15 numerics (each product rounded to the
+ * input type, fp32 accumulate); 1..4 = matrix-core (MFMA) kernel: exact products, fp32 accumulate.
+ * verbose != 0 prints the reference's stage lines to stdout.  stats may be NULL.
+ * Synchronous with respect to the host on return (the reference ends with cudaDeviceSynchronize, :1158). */
+int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, int verbose,
+                void *stream, bmsp_spgemm_stats *stats);
+
+/* bb_segsort<K,T>(keys, vals, n, segs, length)  -- include/bb_segsort-master/bb_segsort.h:35-192,
+ * instantiated by the reference with K = uint64_t, T = 16-byte task_list_elem (src/bmSparse_SPGEMM.cu:1010).
+ * Sorts every segment [segs[i], segs[i+1]) (last ends at n) ascending by key, in place, STABLY
+ * (bb_segsort is unstable).  d_vals may be NULL (keys only). val_bytes in {4, 8, 16}. */
+int bmsp_segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const int *d_segs,
+                     int64_t num_segs, void *stream);
+
+/* ---- row-panel sharding (new; the reference is single-GPU).  One process per GPU: each rank calls these
+ *      with its own rank id; the exchange of panels is done by the host side over RCCL. ---------------- */
+
+/* Splits A's block-rows into `parts` contiguous panels balanced by candidate-task count
+ * (sum over the panel's A blocks of B's blocks in the matching block-row).  bounds receives parts+1
+ * block-row indices. */
+int bmsp_partition_rows(bmsp_matrix_t A, bmsp_matrix_t B, int parts, int64_t *bounds);
+/* The sub-matrix of block-rows [brow_begin, brow_end) as a matrix that borrows m's arrays (no copy);
+ * num_rows stays global so keys stay global.  Free the view before m. */
+int bmsp_matrix_row_panel(bmsp_matrix_t m, int64_t brow_begin, int64_t brow_end, bmsp_matrix_t *view);
+/* Concatenates `parts` row panels (each a product of bmsp_spgemm on a panel, given by its four device arrays)
+ * into one matrix, re-basing offsets.  Arrays of pointers/sizes are host arrays of length parts. */
+int bmsp_matrix_concat_panels(int num_rows, int num_cols, int parts, const int64_t *block_nums,
+                              const int64_t *nnzs, uint64_t *const *d_keys, uint64_t *const *d_bmps,
+                              uint64_t *const *d_offsets, void *const *d_values, bmsp_dtype dtype,
+                              bmsp_matrix_t *out);
+
+/* ---- host CSR (class CSRMatrix, include/CSRMatrix.h:13-21; declared only in the reference; backed by
+ *      cusp::csr_matrix<int,float,host_memory> and cusp::multiply) ---------------------------------- */
+int bmsp_csr_from_mtx(const char *path, bmsp_csr_t *out);                    /* CSRMatrix(std::string) */
+int bmsp_csr_from_arrays(int num_rows, int num_cols, int64_t nnz, const int *row_offsets, const int *cols,
+                         const float *vals, bmsp_csr_t *out);                /* CSRMatrix(csr_matrix*) */
+int bmsp_csr_info(bmsp_csr_t m, int *num_rows, int *num_cols, int64_t *nnz);
+int bmsp_csr_arrays(bmsp_csr_t m, const int **row_offsets, const int **cols, const float **vals);
+int bmsp_csr_multiply(bmsp_csr_t A, bmsp_csr_t B, bmsp_csr_t *C);            /* CSRMatrix::multiply */
+int bmsp_csr_spmv(bmsp_csr_t A, const float *x, float *y);
+int bmsp_csr_free(bmsp_csr_t m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMSP_H_ */

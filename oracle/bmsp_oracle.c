@@ -418,7 +418,7 @@ int orc_spgemm(const orc_bmsp *A, const orc_bmsp *B, int exact_products, orc_bms
     /* T_6 + T_9: C layout (SPGEMM.cu:1031-1107) */
     int64_t cs = 0;
     for (int64_t t = 0; t < nt; t++) if (t == 0 || tasks[t].ckey != tasks[t - 1].ckey) cs++;
-    C->num_rows = A->num_rows; C->num_cols = B->num_cols; C->dtype = ORC_F32; C->transposed = 0;
+    C->num_rows = A->num_rows; C->num_cols = B->num_cols; C->dtype = A->dtype == ORC_F64 ? ORC_F64 : ORC_F32; C->transposed = 0;
     C->block_num = cs;
     C->keys = malloc(8 * (cs ? cs : 1)); C->bmps = calloc(cs ? cs : 1, 8); C->offsets = malloc(8 * (cs + 1));
     int64_t *first_task = malloc(sizeof(int64_t) * (cs + 1)); /* inclusive ends, stored shifted by one */
@@ -437,7 +437,8 @@ int orc_spgemm(const orc_bmsp *A, const orc_bmsp *B, int exact_products, orc_bms
     /* T_7: block multiply-accumulate (multiplyV15, SPGEMM.cu:204-291 ; tensor variants :294-733) */
     for (int64_t i = 0; i < cs; i++) {
         float acc[64];
-        for (int l = 0; l < 64; l++) acc[l] = 0.0f;
+        double accd[64]; /* fp64 inputs accumulate in fp64 (the build's bmSpMatrix<double> product) */
+        for (int l = 0; l < 64; l++) { acc[l] = 0.0f; accd[l] = 0.0; }
         for (int64_t t = first_task[i]; t < first_task[i + 1]; t++) {
             int64_t a = tasks[t].a, b = tasks[t].b;
             double ta[64], tb[64];
@@ -461,7 +462,7 @@ int orc_spgemm(const orc_bmsp *A, const orc_bmsp *B, int exact_products, orc_bms
                         float prod = (float)orc_round_to_dtype(av * bv, ORC_F16);
                         acc[l] = acc[l] + prod;
                     } else if (A->dtype == ORC_F64) {
-                        acc[l] = (float)((double)acc[l] + av * bv);
+                        accd[l] = fma(av, bv, accd[l]);
                     } else {
                         /* fp32: one rounding per step; fp16 exact-product path: the product is exact in fp32 */
                         acc[l] = fmaf((float)av, (float)bv, acc[l]);
@@ -471,7 +472,8 @@ int orc_spgemm(const orc_bmsp *A, const orc_bmsp *B, int exact_products, orc_bms
         }
         /* write bitmap-selected entries (SPGEMM.cu:278-287) */
         uint64_t bmp = C->bmps[i]; int64_t w = (int64_t)C->offsets[i];
-        for (int p = 0; p < 64; p++) if (bmp & (1ull << (63 - p))) C->values[w++] = (double)acc[p];
+        for (int p = 0; p < 64; p++)
+            if (bmp & (1ull << (63 - p))) C->values[w++] = A->dtype == ORC_F64 ? accd[p] : (double)acc[p];
     }
     free(first_task); free(tasks); free(pos);
     return 0;

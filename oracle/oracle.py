@@ -58,6 +58,8 @@ def lib():
         L.orc_round_to_dtype.argtypes = [C.c_double, C.c_int]
         L.orc_bmp_product.restype = C.c_uint64
         L.orc_bmp_product.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_bmp_product_empty.restype = C.c_int
+        L.orc_bmp_product_empty.argtypes = [C.c_uint64, C.c_uint64]
         L.orc_bmsp_compare.restype = C.c_double
         L.orc_spmv_f32.argtypes = [C.POINTER(_Bmsp), C.c_void_p, C.c_void_p]
         L.orc_csr_spmv.argtypes = [C.POINTER(_Csr), C.c_void_p, C.c_void_p, C.c_int]

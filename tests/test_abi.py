@@ -1,0 +1,72 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/bmsp.h declares; the host-only
+entry points (MatrixMarket -> CSR) behave; errors are reported, never swallowed."""
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+from conftest import REPO, MTX
+
+
+def header_symbols():
+    text = open(os.path.join(REPO, "include", "bmsp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bmsp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(bmsp):
+    L = bmsp.lib()
+    declared = header_symbols()
+    assert len(declared) >= 30
+    for s in declared:
+        assert hasattr(L, s), "libbmsp.so does not export %s" % s
+    assert sorted(bmsp.SYMBOLS) == declared
+    assert b"gfx950" in L.bmsp_version()
+
+
+def test_host_csr_reader_matches_cusp_semantics(bmsp, oracle):
+    for rel in ("test/coordinate_pattern_symmetric.mtx", "test/coordinate_real_general.mtx", "laplacian/5pt_10x10.mtx",
+                "random_10x10/000_nonzeros.mtx", "random_10x10/030_nonzeros.mtx"):
+        path = os.path.join(MTX, rel)
+        m = bmsp.CSRMatrix.from_mtx(path)
+        nr, nc, ro, cols, vals = m.arrays()
+        ref = oracle.csr_from_coo(oracle.mtx_read(path, strict=True))
+        assert (nr, nc) == (ref.num_rows, ref.num_cols)
+        np.testing.assert_array_equal(ro, ref.row_offsets)
+        np.testing.assert_array_equal(cols, ref.cols)
+        np.testing.assert_array_equal(vals, ref.vals)
+    # suffix handling of the drop-in CLI: "name" and "name.mtx" both resolve (SPMV.cu:257,270)
+    m = bmsp.CSRMatrix.from_mtx(os.path.join(MTX, "real", "A_matrix"))
+    assert m.arrays()[0] == 24
+
+
+def test_errors_are_reported(bmsp):
+    with pytest.raises(bmsp.BmspError) as e:
+        bmsp.CSRMatrix.from_mtx("/nonexistent/file")
+    assert e.value.status == -2 and "cannot open" in str(e.value)
+    bad = os.path.join(REPO, "tests", "golden", "ragusa16_known.json")
+    with pytest.raises(bmsp.BmspError):
+        bmsp.CSRMatrix.from_mtx(bad)
+    with pytest.raises(bmsp.BmspError):
+        bmsp.CSRMatrix.from_arrays(2, 2, [0, 1, 2], [0, 5], [1.0, 1.0])  # column out of range
+
+
+def test_host_bit_helpers_against_bruteforce(tmp_path):
+    exe = str(tmp_path / "bits")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-include", "cmath", os.path.join(REPO, "tests", "host_bits_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout
+
+
+def test_generators_are_deterministic():
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(10, 4, seed=1)
+    n2, _, r2, c2, v2 = gen.rmat(10, 4, seed=1)
+    assert n == 1024 and r.size == c.size == v.size
+    np.testing.assert_array_equal(r, r2); np.testing.assert_array_equal(c, c2); np.testing.assert_array_equal(v, v2)
+    assert np.all(np.diff(r.astype(np.int64) * n + c) > 0)          # sorted, duplicates merged
+    assert set(zip(range(n), range(n))) <= set(zip(r.tolist(), c.tolist()))  # identity present
+    n, _, r, c, v = gen.banded(100, 3)
+    assert r.size == 100 * 7 - 2 * (1 + 2 + 3) and np.all(np.abs(r - c) <= 3) and np.all(np.abs(v) <= 1)
+    # splitmix64 known answer (seed 0 first output of the reference implementation)
+    assert int(gen.splitmix64(np.array([0], dtype=np.uint64))[0]) == 0xE220A8397B1DCDAF

@@ -1,0 +1,414 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar: bit-exact for every integer array (keys, bitmaps, offsets, nnz, block counts) and for values whenever the
+arithmetic is exact or order-identical; fp32 values within 1e-5 relative (the reference authors' own SpMV check
+was abs 1e-5); fp16 within 2^-10 * sum|a*b| + fp32 slack.
+"""
+import json
+import os
+import numpy as np
+import pytest
+from conftest import GOLDEN, MTX
+import util
+
+pytestmark = pytest.mark.gpu
+
+NPDT = {0: np.float32, 1: np.float16, 2: np.float64}
+
+
+def build_both(oracle, bmsp, nr, nc, rows, cols, vals, dtype, transposed):
+    ref = oracle.bmsp_from_coo(oracle.Coo(nr, nc, rows, cols, vals), dtype, transposed)
+    got = bmsp.BmSpMatrix.from_coo(nr, nc, rows, cols, vals, transposed=transposed, dtype=dtype)
+    return ref, got
+
+
+def check_builder(oracle, bmsp, nr, nc, rows, cols, vals, dtype, transposed):
+    ref, got = build_both(oracle, bmsp, nr, nc, rows, cols, vals, dtype, transposed)
+    info = got.info()
+    assert (info["num_rows"], info["num_cols"], info["nnz"], info["block_num"]) == (nr, nc, ref.nnz, ref.block_num)
+    k, b, o, v = got.host_arrays()
+    util.assert_bmsp_equal_exact(ref, k, b, o, v, NPDT[dtype])
+    # dense block-row pointer
+    rp = got.block_row_ptr()
+    nbr = (nr + 7) // 8
+    exp = np.searchsorted((ref.keys >> np.uint64(32)).astype(np.int64), np.arange(nbr + 1), side="left")
+    np.testing.assert_array_equal(rp, exp.astype(np.uint32))
+    return ref, got
+
+
+# ---------------------------------------------------------------------------------------------------------
+# builder (B1/B2/B3/B4)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", util.all_fixture_mtx())
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_builder_from_mtx_fixtures(oracle, bmsp, path, dtype):
+    coo = oracle.mtx_read(path)
+    for transposed in (False, True):
+        ref = oracle.bmsp_from_coo(coo, dtype, transposed)
+        got = bmsp.BmSpMatrix.from_mtx(path, transposed=transposed, dtype=dtype)
+        k, b, o, v = got.host_arrays()
+        util.assert_bmsp_equal_exact(ref, k, b, o, v, NPDT[dtype])
+        # generate_coo round trip (honours the transposed layout)
+        r, c, vals = got.to_coo()
+        back = oracle.bmsp_to_coo(ref)
+        np.testing.assert_array_equal(r, back.rows)
+        np.testing.assert_array_equal(c, back.cols)
+        np.testing.assert_array_equal(vals, back.vals)
+        err, missing = got.compare(coo.rows, coo.cols, [oracle.lib().orc_round_to_dtype(x, dtype) for x in coo.vals])
+        assert err == 0.0 and missing == 0
+
+
+def test_builder_pattern_symmetric_and_suffix(oracle, bmsp):
+    path = os.path.join(MTX, "test", "coordinate_pattern_symmetric.mtx")
+    coo = oracle.mtx_read(path, strict=True)  # CUSP reader semantics: pattern -> 1, mirrored
+    got = bmsp.BmSpMatrix.from_mtx(path)
+    ref = oracle.bmsp_from_coo(coo, 0, False)
+    util.assert_bmsp_equal_exact(ref, *got.host_arrays(), np.float32)
+    got2 = bmsp.BmSpMatrix.from_mtx(os.path.join(MTX, "real", "A_matrix"))  # without ".mtx"
+    assert got2.block_num == 9
+    with pytest.raises(bmsp.BmspError):
+        bmsp.BmSpMatrix.from_mtx("/nonexistent")
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (8, 8, 64), (9, 17, 40), (100, 37, 300), (1000, 1000, 0), (5, 3000, 2000),
+                                   (4096, 4096, 50000), (333, 777, 9000)])
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_builder_random_ragged_and_duplicates(oracle, bmsp, shape, dtype):
+    from pybmsp import gen
+    nr, nc, nnz = shape
+    _, _, r, c, v = gen.random_coo(nr, nc, nnz, seed=nnz + 3)
+    check_builder(oracle, bmsp, nr, nc, r, c, v, dtype, False)
+    check_builder(oracle, bmsp, nr, nc, r, c, v, dtype, True)
+    if nnz:
+        # unsorted input with duplicate coordinates: summed in input order in the matrix's precision
+        rng = np.random.default_rng(nnz)
+        idx = rng.integers(0, r.size, size=r.size * 2)
+        rr, cc, vv = r[idx], c[idx], rng.uniform(-1, 1, idx.size)
+        check_builder(oracle, bmsp, nr, nc, rr, cc, vv, dtype, False)
+
+
+def test_builder_fp16_rounding_and_overflow(oracle, bmsp):
+    g = json.load(open(os.path.join(GOLDEN, "half_rounding.json")))
+    import struct
+    ds = [struct.unpack(">d", bytes.fromhex(h))[0] for h, _ in g["f64_to_f16"]]
+    ds = [d for d in ds if d == d]
+    n = len(ds)
+    rows = np.arange(n) // 30
+    cols = np.arange(n) % 30
+    got = bmsp.BmSpMatrix.from_coo(rows.max() + 1, 30, rows, cols, ds, dtype=1)
+    ref = oracle.bmsp_from_coo(oracle.Coo(rows.max() + 1, 30, rows, cols, ds), 1, False)
+    util.assert_bmsp_equal_exact(ref, *got.host_arrays(), np.float16)  # includes 65520 -> inf, subnormals, ties
+
+
+def test_adopt_arrays_constructor(oracle, bmsp):
+    from pybmsp import gen
+    _, _, r, c, v = gen.random_coo(200, 150, 3000, seed=9)
+    ref = oracle.bmsp_from_coo(oracle.Coo(200, 150, r, c, v), 0, False)
+    m = bmsp.BmSpMatrix.from_arrays(200, 150, ref.keys, ref.bmps, ref.offsets[:-1], ref.values.astype(np.float32))
+    util.assert_bmsp_equal_exact(ref, *m.host_arrays(), np.float32)
+    x = np.ones(150, np.float32)
+    u = bmsp.spmv(m, bmsp.DeviceArray.from_host(x)).to_host()
+    np.testing.assert_allclose(u, oracle.spmv_f32(ref, x), rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SpMV (M1/M2/M3)
+# ---------------------------------------------------------------------------------------------------------
+def check_spmv(oracle, bmsp, nr, nc, r, c, v, xkind="cusp"):
+    from pybmsp import gen
+    ref, got = build_both(oracle, bmsp, nr, nc, r, c, v, 0, False)
+    x = gen.spmv_x(nc, "ones" if xkind == "ones" else "cusp")
+    y_ref = oracle.spmv_f32(ref, x)
+    S = util.scipy_csr(nr, nc, r, c, np.asarray(v, np.float32).astype(np.float64))
+    y64 = S @ x.astype(np.float64)
+    bound = 1e-5 * (abs(S) @ np.abs(x.astype(np.float64))) + 1e-30
+    dx = bmsp.DeviceArray.from_host(x)
+    for batched in (False, True):
+        du = bmsp.DeviceArray(nr, np.float32)
+        assert bmsp.lib().bmsp_memset(du.ptr, 0xFF, nr * 4) == 0  # NaN poison: every row must be written
+        y = bmsp.spmv(got, dx, du, batched=batched).to_host()
+        assert np.all(np.isfinite(y))
+        assert np.all(np.abs(y - y_ref) <= bound + 1e-5 * np.abs(y_ref)), np.max(np.abs(y - y_ref))
+        assert np.all(np.abs(y - y64) <= 2 * bound + 1e-5 * np.abs(y64))
+    return y_ref
+
+
+def test_spmv_ragusa_known_answer(oracle, bmsp):
+    k = json.load(open(os.path.join(GOLDEN, "ragusa16_known.json")))
+    A = bmsp.BmSpMatrix.from_mtx(os.path.join(MTX, "real", "A_matrix.mtx"))
+    for batched in (False, True):
+        u = bmsp.spmv(A, bmsp.DeviceArray.from_host(np.ones(24, np.float32)), batched=batched).to_host()
+        np.testing.assert_array_equal(u, np.array(k["y_ones"], np.float32))
+
+
+@pytest.mark.parametrize("path", util.all_fixture_mtx())
+def test_spmv_fixtures(oracle, bmsp, path):
+    coo = oracle.mtx_read(path)
+    check_spmv(oracle, bmsp, coo.num_rows, coo.num_cols, coo.rows, coo.cols, coo.vals)  # includes empty rows / ragged edges
+
+
+@pytest.mark.parametrize("case", ["banded", "rmat", "ragged", "empty_rows", "wide"])
+def test_spmv_synthetic(oracle, bmsp, case):
+    from pybmsp import gen
+    if case == "banded":
+        nr, nc, r, c, v = gen.banded(5000, 8)
+    elif case == "rmat":
+        nr, nc, r, c, v = gen.rmat(12, 8)
+    elif case == "ragged":
+        nr, nc, r, c, v = gen.random_coo(1003, 517, 20000, seed=4)
+    elif case == "empty_rows":
+        nr, nc, r, c, v = gen.random_coo(4000, 4000, 300, seed=5)  # most block-rows empty (reference bug)
+    else:
+        nr, nc, r, c, v = gen.random_coo(16, 50000, 60000, seed=6)  # two block-rows with thousands of tiles
+    check_spmv(oracle, bmsp, nr, nc, r, c, v)
+    check_spmv(oracle, bmsp, nr, nc, r, c, v, "ones")
+
+
+def test_spmv_linearity_large(bmsp):
+    """size-independent property at a BASELINE-scale input (webbase-1M-like R-MAT): A(x+y) = Ax + Ay, and
+    A*1 equals the row sums computed on the host."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(18, 4)
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    rowsum = np.bincount(r, weights=np.asarray(v, np.float32).astype(np.float64), minlength=n)
+    ones = bmsp.DeviceArray.from_host(np.ones(n, np.float32))
+    for batched in (False, True):
+        u = bmsp.spmv(A, ones, batched=batched).to_host()
+        np.testing.assert_allclose(u, rowsum, rtol=1e-5, atol=1e-6)
+    x = gen.spmv_x(n, "cusp")
+    y = ((np.arange(n) % 7) - 3).astype(np.float32)
+    ax = bmsp.spmv(A, bmsp.DeviceArray.from_host(x)).to_host().astype(np.float64)
+    ay = bmsp.spmv(A, bmsp.DeviceArray.from_host(y)).to_host().astype(np.float64)
+    axy = bmsp.spmv(A, bmsp.DeviceArray.from_host(x + y)).to_host().astype(np.float64)
+    absrow = np.bincount(r, weights=np.abs(v) * 20, minlength=n)
+    assert np.all(np.abs(axy - (ax + ay)) <= 1e-5 * absrow + 1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SpGEMM (G1..G9) and the segmented sort (S1)
+# ---------------------------------------------------------------------------------------------------------
+def check_spgemm(oracle, bmsp, A_coo, B_coo, dtype, mode, tc, exact_expected=False):
+    (ar, ac, r1, c1, v1), (br, bc, r2, c2, v2) = A_coo, B_coo
+    refA = oracle.bmsp_from_coo(oracle.Coo(ar, ac, r1, c1, v1), dtype, False)
+    refB = oracle.bmsp_from_coo(oracle.Coo(br, bc, r2, c2, v2), dtype, True)
+    A = bmsp.BmSpMatrix.from_coo(ar, ac, r1, c1, v1, transposed=False, dtype=dtype)
+    B = bmsp.BmSpMatrix.from_coo(br, bc, r2, c2, v2, transposed=True, dtype=dtype)
+    mfma = tc != 5 and dtype == 1
+    refC, rst = oracle.spgemm(refA, refB, exact_products=mfma)
+    Cm, st = bmsp.spgemm(A, B, mode=mode, tc_version=tc)
+    # stage counters and structure: bit-exact
+    assert st["task_list_size"] == rst["task_list_size"]
+    assert st["bmp_reduction"] == rst["bmp_reduction"]
+    assert st["surviving_tasks"] == rst["surviving_tasks"]
+    assert st["c_blocks"] == rst["c_blocks"] and st["c_nnz"] == rst["c_nnz"]
+    info = Cm.info()
+    assert (info["num_rows"], info["num_cols"], info["block_num"], info["nnz"], info["transposed"]) == (ar, bc, refC.block_num, refC.nnz, 0)
+    k, b, o, v = Cm.host_arrays()
+    np.testing.assert_array_equal(k, refC.keys)
+    np.testing.assert_array_equal(b, refC.bmps)
+    np.testing.assert_array_equal(o, refC.offsets)
+    ref_vals = refC.values
+    if exact_expected or (not mfma):
+        # same operation order as the oracle (tasks k-ascending, k = 0..7 inside a task): bit-exact
+        np.testing.assert_array_equal(v.astype(np.float64), ref_vals)
+    else:
+        # matrix-core path: exact products, hardware accumulation order -> stated fp16 tolerance
+        Aabs = util.scipy_csr(ar, ac, *[getattr(oracle.bmsp_to_coo(refA), n) for n in ("rows", "cols", "vals")])
+        Bn = oracle.bmsp_to_coo(refB)
+        Babs = util.scipy_csr(br, bc, Bn.rows, Bn.cols, Bn.vals)
+        ref64 = (Aabs @ Babs).todok()
+        mag = (abs(Aabs) @ abs(Babs)).todok()
+        got = util.bmsp_host_to_dok(ar, bc, k, b, o, v)
+        for (i, j), val in got.items():
+            assert abs(val - ref64.get((i, j), 0.0)) <= 2.0 ** -10 * mag.get((i, j), 0.0) + 1e-6, (i, j, val)
+        np.testing.assert_allclose(v.astype(np.float64), ref_vals, rtol=2e-3, atol=1e-6)
+    return st
+
+
+def test_spgemm_ragusa_known_answers(oracle, bmsp):
+    k = json.load(open(os.path.join(GOLDEN, "ragusa16_known.json")))
+    pa, pb = os.path.join(MTX, "real", "A_matrix.mtx"), os.path.join(MTX, "real", "B_matrix.mtx")
+    for dtype in (0, 1):
+        A = bmsp.BmSpMatrix.from_mtx(pa, False, dtype)
+        for name, p in (("AxB", pb), ("AxA", pa)):
+            B = bmsp.BmSpMatrix.from_mtx(p, True, dtype)
+            for mode in (0, 1, 2):
+                for tc in (5, 4, 1):
+                    Cm, st = bmsp.spgemm(A, B, mode=mode, tc_version=tc)
+                    ka = k[name]
+                    assert (st["task_list_size"], st["surviving_tasks"], st["c_blocks"], st["c_nnz"]) == (27, 27, 9, 255)
+                    kk, bb, oo, vv = Cm.host_arrays()
+                    assert ["%016x" % x for x in kk] == ka["c_keys"] and ["%016x" % x for x in bb] == ka["c_bmps"]
+                    assert float(vv.sum()) == ka["sum"] and float(vv.max()) == 51.0  # integer-exact in fp32 AND fp16
+                    d = util.bmsp_host_to_dok(24, 24, kk, bb, oo, vv)
+                    assert sorted([i, j, val] for (i, j), val in d.items()) == ka["entries"]
+
+
+@pytest.mark.parametrize("path", [p for p in util.all_fixture_mtx() if "real_general" not in p])
+@pytest.mark.parametrize("dtype,tc", [(0, 5), (1, 5), (1, 4)])
+def test_spgemm_fixtures_square(oracle, bmsp, path, dtype, tc):
+    coo = oracle.mtx_read(path)
+    if coo.num_rows != coo.num_cols:
+        pytest.skip("not square")
+    t = (coo.num_rows, coo.num_cols, coo.rows, coo.cols, coo.vals)
+    for mode in (2, 1):
+        # integer-valued fixtures: products and sums are exact in fp16/fp32 -> even the MFMA path is bit-exact
+        check_spgemm(oracle, bmsp, t, t, dtype, mode, tc, exact_expected=True)
+
+
+@pytest.mark.parametrize("case", ["rect", "banded", "rmat", "empty_rows", "filtered", "single_block"])
+@pytest.mark.parametrize("dtype,tc", [(0, 5), (1, 5), (1, 4), (2, 5)])
+def test_spgemm_synthetic(oracle, bmsp, case, dtype, tc):
+    from pybmsp import gen
+    if case == "rect":
+        A = gen.random_coo(70, 45, 900, seed=1, lo=0, hi=1)
+        B = gen.random_coo(45, 123, 1100, seed=2, lo=0, hi=1)
+    elif case == "banded":
+        A = B = gen.banded(600, 5)
+    elif case == "rmat":
+        A = B = gen.rmat(10, 6)
+    elif case == "empty_rows":
+        A = gen.random_coo(500, 500, 400, seed=3, lo=0, hi=1)   # B has many empty block-rows; fan-out 0 tasks
+        B = gen.random_coo(500, 500, 150, seed=4, lo=0, hi=1)
+    elif case == "filtered":
+        # A uses only even k, B only odd k inside every tile: every candidate pair dies in the bitmap filter
+        n = 256
+        ra = np.repeat(np.arange(n), 2); ca = (ra // 8) * 8 + np.tile([0, 2], n)
+        rb = np.repeat(np.arange(n), 2); rb = (rb // 8) * 8 + np.tile([1, 3], n); cb = np.repeat(np.arange(n), 2)
+        A = (n, n, ra, ca, np.ones(ra.size)); B = (n, n, rb, cb, np.ones(rb.size))
+    else:
+        A = (8, 8, np.array([0, 3]), np.array([1, 1]), np.array([2.0, 3.0]))
+        B = (8, 8, np.array([1, 1]), np.array([0, 7]), np.array([5.0, 7.0]))
+    for mode in (2, 1):
+        st = check_spgemm(oracle, bmsp, A, B, dtype, mode, tc)
+    if case == "filtered":
+        assert st["surviving_tasks"] == 0 and st["c_blocks"] == 0 and st["bmp_reduction"] == st["task_list_size"] > 0
+
+
+def test_spgemm_chain_feeds_back(oracle, bmsp):
+    """C is a valid A operand (normal layout, keys ascending): (A*A)*A runs and matches the oracle chain."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.banded(400, 3)
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    At = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True)
+    C1, _ = bmsp.spgemm(A, At)
+    C2, _ = bmsp.spgemm(C1, At)
+    oA = oracle.bmsp_from_coo(oracle.Coo(n, n, r, c, v), 0, False)
+    oAt = oracle.bmsp_from_coo(oracle.Coo(n, n, r, c, v), 0, True)
+    oC1, _ = oracle.spgemm(oA, oAt)
+    oC2, _ = oracle.spgemm(oC1, oAt)
+    k, b, o, vals = C2.host_arrays()
+    np.testing.assert_array_equal(k, oC2.keys)
+    np.testing.assert_array_equal(b, oC2.bmps)
+    np.testing.assert_array_equal(vals.astype(np.float64), oC2.values)
+
+
+def test_spgemm_argument_errors(bmsp):
+    from pybmsp import gen
+    n, _, r, c, v = gen.banded(64, 2)
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    At = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True)
+    with pytest.raises(bmsp.BmspError):
+        bmsp.spgemm(A, A)       # B not transposed
+    with pytest.raises(bmsp.BmspError):
+        bmsp.spgemm(At, At)     # A transposed
+    W = bmsp.BmSpMatrix.from_coo(32, 32, [0], [0], [1.0], transposed=True)
+    with pytest.raises(bmsp.BmspError):
+        bmsp.spgemm(A, W)       # shape mismatch
+    with pytest.raises(bmsp.BmspError):
+        bmsp.spmv(At, bmsp.DeviceArray.from_host(np.ones(n, np.float32)))
+
+
+def test_spgemm_properties_large(bmsp):
+    """BASELINE-scale structural properties without the oracle: C = A*I reproduces A; symbolic nnz of A*A
+    equals the pattern product computed by scipy; row sums of C equal A*(A*1)."""
+    from pybmsp import gen
+    import scipy.sparse as sp
+    n, _, r, c, v = gen.rmat(15, 6)
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    It = bmsp.BmSpMatrix.from_coo(n, n, np.arange(n), np.arange(n), np.ones(n), transposed=True)
+    Cm, st = bmsp.spgemm(A, It, mode=1)
+    ka, ba, oa, va = A.host_arrays()
+    kc, bc, oc, vc = Cm.host_arrays()
+    np.testing.assert_array_equal(ka, kc); np.testing.assert_array_equal(ba, bc)
+    np.testing.assert_array_equal(oa, oc); np.testing.assert_array_equal(va, vc)
+    At = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True)
+    for mode in (1, 2):
+        C2, st2 = bmsp.spgemm(A, At, mode=mode)
+        S = sp.coo_matrix((np.ones(r.size), (r, c)), shape=(n, n)).tocsr()
+        pat = (S @ S)
+        assert st2["c_nnz"] == pat.nnz
+        rr, cc, vv = C2.to_coo()
+        S32 = sp.coo_matrix((np.asarray(v, np.float32).astype(np.float64), (r, c)), shape=(n, n)).tocsr()
+        ref = (S32 @ S32).tocoo()
+        key_ref = ref.row.astype(np.int64) * n + ref.col
+        order = np.argsort(key_ref)
+        np.testing.assert_array_equal(rr.astype(np.int64) * n + cc, key_ref[order])
+        np.testing.assert_allclose(vv, ref.data[order], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("val_bytes", [0, 4, 8, 16])
+def test_segsort_against_gold(oracle, bmsp, val_bytes):
+    rng = np.random.default_rng(val_bytes)
+    n = 200000
+    keys = rng.integers(0, 1 << 40, n).astype(np.uint64)
+    keys[: n // 2] &= np.uint64(0xFF)  # many ties: stability matters
+    cuts = np.unique(np.concatenate([[0], rng.integers(0, n, 3000), [5, 6, 7, 8, 100000, 100001]])).astype(np.int64)
+    pay = np.stack([np.arange(n, dtype=np.uint64), keys ^ np.uint64(0xABCDEF)], axis=1)
+    gk, gv = oracle.segsort(keys, pay, cuts)
+    dk = bmsp.DeviceArray.from_host(keys)
+    if val_bytes == 0:
+        dv = None
+    elif val_bytes == 4:
+        dv = bmsp.DeviceArray.from_host(pay[:, 0].astype(np.uint32))
+    elif val_bytes == 8:
+        dv = bmsp.DeviceArray.from_host(pay[:, 0].copy())
+    else:
+        dv = bmsp.DeviceArray.from_host(pay.reshape(-1))
+        dv.dtype = np.dtype([("a", np.uint64), ("b", np.uint64)]); dv.n = n
+    bmsp.segsort(dk, dv, bmsp.DeviceArray.from_host(cuts.astype(np.int32)))
+    np.testing.assert_array_equal(dk.to_host(), gk)
+    if val_bytes == 4:
+        np.testing.assert_array_equal(dv.to_host(), gv[:, 0].astype(np.uint32))
+    elif val_bytes == 8:
+        np.testing.assert_array_equal(dv.to_host(), gv[:, 0])
+    elif val_bytes == 16:
+        out = dv.to_host()
+        np.testing.assert_array_equal(out["a"], gv[:, 0]); np.testing.assert_array_equal(out["b"], gv[:, 1])
+
+
+def test_csr_matrix_multiply_on_gpu(oracle, bmsp):
+    """CSRMatrix(std::string) + multiply (include/CSRMatrix.h:13-21) against the cusp restatement."""
+    path = os.path.join(MTX, "laplacian", "9pt_10x10.mtx")
+    m = bmsp.CSRMatrix.from_mtx(path)
+    Cm = m.multiply(m)
+    nr, nc, ro, cols, vals = Cm.arrays()
+    ref, _ = oracle.csr_spgemm(oracle.csr_from_coo(oracle.mtx_read(path, strict=True)), oracle.csr_from_coo(oracle.mtx_read(path, strict=True)), 1)
+    np.testing.assert_array_equal(ro, ref.row_offsets)
+    for i in range(nr):  # cusp leaves columns unsorted inside a row (csr_spgemm.h:153); compare as sets
+        a = sorted(zip(cols[ro[i]:ro[i + 1]].tolist(), vals[ro[i]:ro[i + 1]].tolist()))
+        bb = sorted(zip(ref.cols[ref.row_offsets[i]:ref.row_offsets[i + 1]].tolist(), ref.vals[ref.row_offsets[i]:ref.row_offsets[i + 1]].tolist()))
+        assert a == bb
+    x = (np.arange(nc) % 10).astype(np.float32)
+    np.testing.assert_allclose(m.spmv(x), oracle.csr_spmv(oracle.csr_from_coo(oracle.mtx_read(path, strict=True)), x, 1), rtol=1e-6)
+
+
+def test_row_panels_concat_equals_whole(oracle, bmsp):
+    """the multi-GPU decomposition on one device: panel products concatenated == the whole product."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(12, 6)
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    Bt = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True)
+    whole, _ = bmsp.spgemm(A, Bt)
+    for parts in (1, 2, 3, 8):
+        bounds = bmsp.partition_rows(A, Bt, parts)
+        assert bounds[0] == 0 and bounds[-1] == (n + 7) // 8 and np.all(np.diff(bounds) >= 0)
+        panels, keep = [], []
+        for p in range(parts):
+            view = A.row_panel(bounds[p], bounds[p + 1])
+            Cp, _ = bmsp.spgemm(view, Bt)
+            keep.append((view, Cp))
+            panels.append(Cp.device_arrays())
+        cat = bmsp.concat_panels(n, n, panels)
+        for x, y in zip(cat.host_arrays(), whole.host_arrays()):
+            np.testing.assert_array_equal(x, y)
