@@ -23,6 +23,8 @@ struct bmsp_matrix_s {
     // sweep plan of the SpMV (see spmv.hip): chunk descriptors
     uint32_t *spmv_chunks = nullptr;
     int64_t spmv_num_chunks = 0;
+    int64_t spmv_plan_long = 0;
+    size_t spmv_plan_off_cnt = 0, spmv_plan_off_carry = 0;
     // a row-panel view points into its parent
     int64_t view_block_begin = 0;
 

@@ -1,20 +1,37 @@
 // spmv.hip -- u = A * v on the bmSparse format, gfx950 / wave64.
 //
-// Reference: bmSparse_SpMV<VI,VO>, src/bmSparse_SPMV.cu:191-230 with spmv_kernel (:153-189, one 64-thread
-// block per block-row, one lane per tile ELEMENT, serial loop over the row's tiles) and spmv_kernel_new
-// (:84-150, the "batched" path: several tiles per step, wide lane reduction).
+// Reference: bmSparse_SpMV<VI,VO>, src/bmSparse_SPMV.cu:191-230 with spmv_kernel (:153-189, one 64-thread block per
+// block-row, one lane per tile ELEMENT, serial loop over the row's tiles) and spmv_kernel_new (:84-150, the "batched"
+// path: several tiles per step, wide lane reduction).  Both rebuild a block-row pointer on every call (:199-206).
 //
-// MI355X design: the unit of work is a tile ROW (one byte of the bitmap).  A lane owns row r of a tile:
-// it takes byte r of the bitmap, ranks it with one popcount of the bits in front of it, and walks the set
-// bits of that byte, multiplying consecutive values by the matching x entries.  Tiles are 1-8 % dense on
-// graph matrices, so a lane per element (the reference's mapping) leaves >90 % of a wave64 idle, while a
-// lane per tile row keeps the value loads of a tile contiguous across the 8 lanes of a group.
-//   variant 0: an 8-lane group sweeps one block-row, no cross-lane traffic at all;
-//   variant 1: a whole wave sweeps one block-row 8 tiles at a time and folds the eight partial rows with
-//              xor-shuffles (wavefront reduction) -- for block-rows with many tiles.
-// The dense block-row pointer is built once per matrix (builder.hip), not per call as the reference does.
+// MI355X design (variant 0, the default): the block-vector sweep.
+//   * A per-matrix SWEEP PLAN (built once, cached like the block-row pointer) cuts the block array into wave-sized
+//     work items.  Short block-rows are grouped into items aligned to block-row boundaries (<= 64 block-rows inside
+//     one aligned 64-row window, < 256 tiles), so an item owns a contiguous slice of u outright.  A block-row with
+//     more than 128 tiles (hub rows of web / R-MAT graphs) is cut into 128-tile items of its own.
+//   * One wave per item.  Lane l loads key / bitmap / offset of tiles l and l+64 of a 128-tile batch: three fully
+//     coalesced streams, no dependent pointer chase.  Work per lane is one tile whatever the row lengths are, so
+//     skewed graphs stay balanced.
+//       sparse tiles (<= 8 stored values): the lane peels the elements off the top of the bitmap and issues all their
+//         value / x gathers back to back (buffer loads against wave-uniform descriptors; an absent element points out
+//         of range and reads 0, so there is no branch and no 64-bit address arithmetic), then adds the products into
+//         the item's u tile in LDS (64 block-rows x 8 rows per wave).
+//       dense tiles: queued in LDS and swept by the whole wave, lane p = tile position p (contiguous value loads),
+//         8-lane DPP row sums, one LDS add per tile row.
+//   * Short items store their u slice with coalesced stores (empty block-rows come out as zeros for free).
+//     Long-row items park their 8 partial sums in a carry slot and bump a per-row arrival counter; the last wave to
+//     arrive folds all slots in a fixed order and writes the row (write-through stores + agent-scope counter,
+//     self-resetting), so the whole product is ONE launch.
+//   Measured alternatives (DESIGN.md "SpMV design log"): ds_add_f32 costs ~3 cycles per ACTIVE lane on gfx950 while
+//   integer LDS atomics run at full rate (experiments/lds_atomic_rate.hip); an atomic-free pull formulation and an
+//   integer-atomic counting-sort exchange were both built and were slower (2-3x the instructions per tile, lower
+//   occupancy).  This kernel needs ~2.8 wave instructions per tile, inside the budget of an HBM-bound sweep.
+// variant 1 ("batched"): a whole wave sweeps one block-row, 8 tiles x 8 tile rows per step, and folds the eight partial
+//     rows with xor-shuffles (wavefront reduction): contiguous value loads per tile, for matrices with dense tiles.
+// variant 2: 8-lane group per block-row (kept for comparison).
 #include "matrix.h"
 #include "prims.hip.h"
+#include <cstdlib>
 
 namespace bmsp {
 namespace {
@@ -24,6 +41,297 @@ struct Acc { using type = float; };
 template <>
 struct Acc<double> { using type = double; };
 
+constexpr uint32_t kItemTiles = 128;  // tile budget of an item (short items hold < 2x this, long-row items exactly this)
+constexpr uint32_t kItemRows = 64;    // block-rows per item window (u tile = 64 x 8 accumulators)
+
+struct SweepItem {      // 32 bytes, read with scalar loads
+    uint32_t row_begin, row_end;  // block-rows [row_begin, row_end)
+    uint32_t blk_begin, blk_end;  // tiles [blk_begin, blk_end)
+    uint32_t first_item;          // long rows: index of the row's first item
+    uint32_t num_items;           // long rows: number of items of the row; 0 = short item
+    uint32_t long_idx;            // long rows: arrival counter index
+    uint32_t pad;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// plan construction (once per matrix)
+// ---------------------------------------------------------------------------------------------------------
+struct RowClass {
+    const uint32_t *rowptr;
+    const uint64_t *offsets;
+    uint32_t nbr;
+    __device__ bool is_long(uint32_t r) const { return rowptr[r + 1] - rowptr[r] > kItemTiles; }
+    __device__ bool starts(uint32_t r) const
+    {
+        if (r == 0 || (r % kItemRows) == 0) return true;
+        if (rowptr[r] / kItemTiles != rowptr[r - 1] / kItemTiles) return true;
+        return is_long(r) || is_long(r - 1);
+    }
+    // packed counts: low 36 bits = items contributed by row r, high bits = 1 if long
+    __device__ uint64_t operator()(uint64_t r64) const
+    {
+        if (r64 >= nbr) return 0;
+        uint32_t r = (uint32_t)r64;
+        if (is_long(r)) {
+            uint32_t len = rowptr[r + 1] - rowptr[r];
+            return (uint64_t)((len + kItemTiles - 1) / kItemTiles) | (1ull << 36);
+        }
+        return starts(r) ? 1ull : 0ull;
+    }
+};
+struct PlanTotals {
+    uint64_t n;
+    uint64_t *out;
+    __device__ void operator()(uint64_t i, uint64_t ex) const
+    {
+        if (i == n) *out = ex;
+    }
+};
+struct PlanFill {
+    RowClass rc;
+    uint32_t nb;
+    SweepItem *items;
+    __device__ void operator()(uint64_t r64, uint64_t ex) const
+    {
+        const uint32_t base = (uint32_t)(ex & ((1ull << 36) - 1)), lbase = (uint32_t)(ex >> 36);
+        const uint32_t r = (uint32_t)r64;
+        if (r == rc.nbr) {
+            if (rc.nbr && !rc.is_long(rc.nbr - 1)) { items[base - 1].row_end = rc.nbr; items[base - 1].blk_end = nb; }
+            return;
+        }
+        const bool lg = rc.is_long(r), st = lg || rc.starts(r);
+        if (!st) return;
+        const uint32_t s = rc.rowptr[r], e = rc.rowptr[r + 1];
+        if (r > 0 && !rc.is_long(r - 1)) { items[base - 1].row_end = r; items[base - 1].blk_end = s; }
+        if (lg) {
+            const uint32_t cnt = (e - s + kItemTiles - 1) / kItemTiles;
+            for (uint32_t c = 0; c < cnt; c++) {
+                SweepItem it;
+                it.row_begin = r; it.row_end = r + 1;
+                it.blk_begin = s + c * kItemTiles;
+                it.blk_end = min(e, s + (c + 1) * kItemTiles);
+                it.first_item = base; it.num_items = cnt; it.long_idx = lbase; it.pad = 0;
+                items[base + c] = it;
+            }
+        } else {
+            items[base].row_begin = r; items[base].blk_begin = s;
+            items[base].first_item = base; items[base].num_items = 0; items[base].long_idx = 0xffffffffu; items[base].pad = 0;
+        }
+    }
+};
+
+struct SweepPlan {
+    SweepItem *items;
+    uint32_t num_items, num_long;
+    void *carry;         // num_items x 8 accumulators (only long items use their slot)
+    uint32_t *counters;  // num_long arrival counters, zero between calls
+};
+
+void build_plan(bmsp_matrix_s *A, hipStream_t st)
+{
+    if (A->spmv_chunks) return;
+    ensure_rowptr(A, st);
+    const uint32_t nbr = (uint32_t)A->num_block_rows(), nb = (uint32_t)A->block_num;
+    RowClass rc{A->rowptr, A->offsets, nbr};
+    DevBuf<uint64_t> tot(1);
+    device_exclusive_scan<uint64_t>(rc, PlanTotals{nbr, tot.p}, (uint64_t)nbr + 1, st);
+    const uint64_t packed = read_back(tot.p, st);
+    const uint32_t n_items = (uint32_t)(packed & ((1ull << 36) - 1)), n_long = (uint32_t)(packed >> 36);
+    // one allocation: header | items | counters | carry
+    const size_t acc_sz = A->dtype == BMSP_F64 ? 8 : 4;
+    const size_t off_items = 64, off_cnt = off_items + sizeof(SweepItem) * (size_t)n_items;
+    const size_t off_carry = (off_cnt + 4 * (size_t)n_long + 63) & ~size_t(63);
+    const size_t total = off_carry + acc_sz * 8 * (size_t)n_items + 64;
+    char *mem = (char *)pool_alloc(total);
+    BMSP_HIP(hipMemsetAsync(mem, 0, total, st));
+    uint32_t hdr[4] = {n_items, n_long, (uint32_t)off_cnt, (uint32_t)off_carry};
+    BMSP_HIP(hipMemcpyAsync(mem, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
+    if (nbr) device_exclusive_scan<uint64_t>(rc, PlanFill{rc, nb, (SweepItem *)(mem + off_items)}, (uint64_t)nbr + 1, st);
+    BMSP_HIP(hipStreamSynchronize(st));
+    A->spmv_chunks = (uint32_t *)mem;
+    A->spmv_num_chunks = n_items;
+    A->spmv_plan_long = n_long;
+    A->spmv_plan_off_cnt = off_cnt;
+    A->spmv_plan_off_carry = off_carry;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the sweep kernel
+// ---------------------------------------------------------------------------------------------------------
+// Buffer (SRSRC) loads: 32-bit byte offsets against a wave-uniform descriptor, and an out-of-range offset returns 0.
+// That removes the 64-bit address arithmetic and -- by steering absent elements to offset ~0 -- every exec-mask branch
+// of the predicated gathers; x's descriptor ends at num_cols, so the ragged last block column reads as 0 by itself.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr uint32_t kOob = 0xffffffffu;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+template <typename T>
+struct Buf;
+template <>
+struct Buf<float> {
+    static __device__ __forceinline__ float ld(rsrc_t r, uint32_t off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
+};
+template <>
+struct Buf<_Float16> {
+    static __device__ __forceinline__ float ld(rsrc_t r, uint32_t off) { return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0)); }
+};
+template <>
+struct Buf<double> {
+    static __device__ __forceinline__ double ld(rsrc_t r, uint32_t off) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); }
+};
+
+constexpr int kSparseMax = 8;   // tiles with more stored values than this go to the wave-wide dense pass
+constexpr int kDenseTrip = 8;   // dense tiles per trip of the wave-wide pass
+
+template <typename A>
+__device__ __forceinline__ void lds_add(A *p, A v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // ds_add_f32 / ds_add_f64
+}
+
+// sum over the 8 lanes of a tile row (aligned groups of 8 lanes) with DPP adds -- no LDS traffic
+__device__ __forceinline__ float row8_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm 1,0,3,2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm 2,3,0,1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ double row8_sum(double v)
+{
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+
+// the (up to kSparseMax) stored elements of one tile, handled by ONE lane: positions peeled off the top of the bitmap,
+// all value / x loads issued back to back, then the LDS adds (exec-masked: ds_add_f32 is priced per active lane)
+template <typename T, typename A>
+__device__ __forceinline__ void sparse_tile(uint64_t bm, uint32_t voff, uint32_t xbase, A *__restrict__ trow, rsrc_t rv, rsrc_t rx)
+{
+    A a[kSparseMax], xv[kSparseMax];
+    uint32_t pr[kSparseMax];
+    bool has[kSparseMax];
+#pragma unroll
+    for (int j = 0; j < kSparseMax; j++) {
+        has[j] = bm != 0;
+        const uint32_t p = (uint32_t)__clzll((long long)bm) & 63u;
+        bm &= ~(0x8000000000000000ull >> p);
+        pr[j] = p >> 3;
+        a[j] = Buf<T>::ld(rv, has[j] ? voff + (uint32_t)(j * sizeof(T)) : kOob);
+        xv[j] = Buf<T>::ld(rx, has[j] ? xbase + (p & 7u) * (uint32_t)sizeof(T) : kOob);
+    }
+#pragma unroll
+    for (int j = 0; j < kSparseMax; j++)
+        if (has[j]) lds_add(trow + pr[j], a[j] * xv[j]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *__restrict__ items, uint32_t num_items,
+                                                              const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bmps,
+                                                              const uint64_t *__restrict__ offsets, const T *__restrict__ values,
+                                                              const T *__restrict__ x, typename Acc<T>::type *__restrict__ y,
+                                                              typename Acc<T>::type *__restrict__ carry, uint32_t *__restrict__ counters,
+                                                              uint32_t num_rows, uint32_t num_cols, uint32_t values_bytes)
+{
+    using A = typename Acc<T>::type;
+    __shared__ A tile_all[4][kItemRows * 8];
+    __shared__ uint64_t q_bmp_all[4][kItemTiles];
+    __shared__ uint32_t q_off_all[4][kItemTiles], q_xb_all[4][kItemTiles], q_tb_all[4][kItemTiles];
+    const int w = wave_id(), lane = lane_id();
+    const uint32_t item_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
+    if (item_id >= num_items) return;
+    A *tile = tile_all[w];
+    uint64_t *q_bmp = q_bmp_all[w];
+    uint32_t *q_off = q_off_all[w], *q_xb = q_xb_all[w], *q_tb = q_tb_all[w];
+    const SweepItem it = items[item_id];
+    const rsrc_t rv = make_rsrc(values, values_bytes), rx = make_rsrc(x, num_cols * (uint32_t)sizeof(T));
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int k = 0; k < 8; k++) tile[k * 64 + lane] = A(0);
+    __builtin_amdgcn_wave_barrier();
+
+    for (uint32_t base = it.blk_begin; base < it.blk_end; base += kItemTiles) {
+        // lane-per-tile: three coalesced streams, two tiles per lane
+        const uint32_t b0 = base + lane, b1 = base + 64 + lane;
+        uint64_t bm0 = 0, bm1 = 0, k0 = (uint64_t)it.row_begin << 32, k1 = k0, o0 = 0, o1 = 0;
+        if (b0 < it.blk_end) { bm0 = bmps[b0]; k0 = keys[b0]; o0 = offsets[b0]; }
+        if (b1 < it.blk_end) { bm1 = bmps[b1]; k1 = keys[b1]; o1 = offsets[b1]; }
+        const uint32_t x0 = key_col(k0) * 8u * (uint32_t)sizeof(T), x1 = key_col(k1) * 8u * (uint32_t)sizeof(T);
+        const uint32_t tb0 = (key_row(k0) - it.row_begin) * 8u, tb1 = (key_row(k1) - it.row_begin) * 8u;
+        const uint32_t vo0 = (uint32_t)o0 * (uint32_t)sizeof(T), vo1 = (uint32_t)o1 * (uint32_t)sizeof(T);
+        // tiles with many stored values are queued for the wave-wide pass
+        const bool d0 = __popcll(bm0) > kSparseMax, d1 = __popcll(bm1) > kSparseMax;
+        const uint64_t m0 = __ballot(d0), m1 = __ballot(d1);
+        const int n0 = __popcll(m0), qn = n0 + __popcll(m1);
+        if (d0) {
+            const int s = __popcll(m0 & lt);
+            q_bmp[s] = bm0; q_off[s] = vo0; q_xb[s] = x0; q_tb[s] = tb0;
+        }
+        if (d1) {
+            const int s = n0 + __popcll(m1 & lt);
+            q_bmp[s] = bm1; q_off[s] = vo1; q_xb[s] = x1; q_tb[s] = tb1;
+        }
+        // sparse tiles: one lane per tile, every load of both tiles in flight before the first LDS add
+        sparse_tile<T, A>(d0 ? 0ull : bm0, vo0, x0, tile + tb0, rv, rx);
+        sparse_tile<T, A>(d1 ? 0ull : bm1, vo1, x1, tile + tb1, rv, rx);
+        __builtin_amdgcn_wave_barrier();
+        // dense tiles: the whole wave per tile, lane p owns tile position p (coalesced value loads), kDenseTrip tiles per trip
+        for (int q = 0; q < qn; q += kDenseTrip) {
+            A pa[kDenseTrip];
+#pragma unroll
+            for (int t = 0; t < kDenseTrip; t++) {
+                const int e = min(q + t, qn - 1);
+                const uint64_t bb = q + t < qn ? q_bmp[e] : 0ull;
+                const bool has = tile_has(bb, lane);
+                const A av = Buf<T>::ld(rv, has ? q_off[e] + (uint32_t)tile_rank(bb, lane) * (uint32_t)sizeof(T) : kOob);
+                const A xx = Buf<T>::ld(rx, has ? q_xb[e] + ((uint32_t)lane & 7u) * (uint32_t)sizeof(T) : kOob);
+                pa[t] = av * xx;
+            }
+#pragma unroll
+            for (int t = 0; t < kDenseTrip; t++) {
+                const int e = min(q + t, qn - 1);
+                const A sum = row8_sum(pa[t]);
+                if (q + t < qn && (lane & 7) == 0 && tile_byte(q_bmp[e], lane >> 3)) lds_add(tile + q_tb[e] + (lane >> 3), sum);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (it.num_items == 0) {
+        // short item: the wave owns u[row_begin*8, row_end*8)
+        const uint32_t n_out = (it.row_end - it.row_begin) * 8u, out0 = it.row_begin * 8u;
+        for (uint32_t e = lane; e < n_out; e += 64)
+            if (out0 + e < num_rows) y[out0 + e] = tile[e];
+        return;
+    }
+    // long row: park the partial sums, the last arriver folds them.  Write-through (sc1) stores + drained vmcnt +
+    // agent-scope counter add; the wave whose add comes last reads every slot with sc1 loads (MI355X_MICROARCH.md
+    // "Valid forms": every store and load of the handed-off bytes sc1, no cache-wide fence -- a release fence per item
+    // writes back the whole L2 thousands of times per launch: measured 10x slower).
+    if (lane < 8) __hip_atomic_store(&carry[(size_t)item_id * 8 + lane], tile[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(&counters[it.long_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != it.num_items - 1) return;
+    // lanes 0..7 own tile row `r`; lane group g = lane/8 walks items g, g+8, ...; fixed order
+    const int r = lane & 7, g = lane >> 3;
+    A sum = 0;
+    for (uint32_t c = g; c < it.num_items; c += 8)
+        sum += __hip_atomic_load(&carry[(size_t)(it.first_item + c) * 8 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) sum += __shfl_xor(sum, d, kWave);
+    const uint32_t row = it.row_begin * 8u + (uint32_t)r;
+    if (g == 0 && row < num_rows) y[row] = sum;
+    if (lane == 0) __hip_atomic_store(&counters[it.long_idx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// block-row kernels (variants 1 and 2)
+// ---------------------------------------------------------------------------------------------------------
 // one tile row: byte = bits of row r (MSB = column 0), vals points at the first stored value of that row
 template <typename T, typename A>
 __device__ __forceinline__ A tile_row_dot(uint32_t byte, const T *__restrict__ vals, const T *__restrict__ x, uint32_t xbase,
@@ -34,18 +342,18 @@ __device__ __forceinline__ A tile_row_dot(uint32_t byte, const T *__restrict__ v
         byte &= ~(0x80u >> c);
         uint32_t col = xbase + (uint32_t)c;
         A a = (A)(*vals++);
-        A xv = col < num_cols ? (A)x[col] : A(0);  // ragged last block column (reference reads past the end)
+        A xv = col < num_cols ? (A)x[col] : A(0);
         acc = __builtin_fma(a, xv, acc);
     }
     return acc;
 }
 
 template <typename T, int LANES_PER_ROW>
-__global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const uint32_t *__restrict__ rowptr, const uint64_t *__restrict__ keys,
-                                                              const uint64_t *__restrict__ bmps, const uint64_t *__restrict__ offsets,
-                                                              const T *__restrict__ values, const T *__restrict__ x,
-                                                              typename Acc<T>::type *__restrict__ y, uint32_t num_rows,
-                                                              uint32_t num_cols, uint32_t num_block_rows)
+__global__ __launch_bounds__(kThreads) void spmv_blockrow_kernel(const uint32_t *__restrict__ rowptr, const uint64_t *__restrict__ keys,
+                                                                 const uint64_t *__restrict__ bmps, const uint64_t *__restrict__ offsets,
+                                                                 const T *__restrict__ values, const T *__restrict__ x,
+                                                                 typename Acc<T>::type *__restrict__ y, uint32_t num_rows,
+                                                                 uint32_t num_cols, uint32_t num_block_rows)
 {
     using A = typename Acc<T>::type;
     constexpr int GROUPS = LANES_PER_ROW / 8;  // tiles in flight per block-row per step
@@ -78,13 +386,26 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
     uint32_t nbr = (uint32_t)A->num_block_rows();
     if (nbr == 0) return;
     if (variant == BMSP_SPMV_BATCHED) {
-        hipLaunchKernelGGL((spmv_sweep_kernel<T, 64>), dim3((nbr + 3) / 4), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps,
+        hipLaunchKernelGGL((spmv_blockrow_kernel<T, 64>), dim3((nbr + 3) / 4), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps,
+                           A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows,
+                           (uint32_t)A->num_cols, nbr);
+    } else if (variant == 2) {
+        hipLaunchKernelGGL((spmv_blockrow_kernel<T, 8>), dim3((nbr + 31) / 32), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps,
+                           A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows,
+                           (uint32_t)A->num_cols, nbr);
+    } else if ((size_t)A->nnz * sizeof(T) >= (1ull << 32) || (size_t)A->num_cols * sizeof(T) >= (1ull << 32)) {
+        // buffer descriptors address 4 GiB; beyond that fall back to the pointer-based block-row kernel
+        hipLaunchKernelGGL((spmv_blockrow_kernel<T, 64>), dim3((nbr + 3) / 4), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps,
                            A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows,
                            (uint32_t)A->num_cols, nbr);
     } else {
-        hipLaunchKernelGGL((spmv_sweep_kernel<T, 8>), dim3((nbr + 31) / 32), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps,
-                           A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows,
-                           (uint32_t)A->num_cols, nbr);
+        build_plan(A, st);
+        const uint32_t n_items = (uint32_t)A->spmv_num_chunks;
+        char *mem = (char *)A->spmv_chunks;
+        hipLaunchKernelGGL((spmv_sweep_kernel<T>), dim3((n_items + 3) / 4), dim3(kThreads), 0, st, (const SweepItem *)(mem + 64), n_items,
+                           A->keys, A->bmps, A->offsets, (const T *)A->values, (const T *)v, (Ac *)u,
+                           (Ac *)(mem + A->spmv_plan_off_carry), (uint32_t *)(mem + A->spmv_plan_off_cnt), (uint32_t)A->num_rows,
+                           (uint32_t)A->num_cols, (uint32_t)((size_t)A->nnz * sizeof(T)));
     }
     BMSP_CHECK_LAUNCH();
 }
@@ -95,6 +416,7 @@ void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st)
 {
     if (A->transposed) fail(BMSP_ERR_INVALID, "SpMV needs a matrix built with transposed=0");
     if (!v || !u) fail(BMSP_ERR_INVALID, "null vector");
+    if (variant < 0 || variant > 2) fail(BMSP_ERR_INVALID, "unknown SpMV variant %d", variant);
     ensure_rowptr(A, st);
     switch (A->dtype) {
     case BMSP_F32: launch<float>(A, v, u, variant, st); break;

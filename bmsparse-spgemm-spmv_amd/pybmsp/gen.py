@@ -72,6 +72,23 @@ def rmat(scale, edge_factor, a=0.57, b=0.19, c=0.19, seed=1, add_identity=True, 
     return n, n, (uk // np.uint64(n)).astype(np.int32), (uk % np.uint64(n)).astype(np.int32), v
 
 
+def cage_like(n, per_row=15.6, local_frac=0.75, half_bw=24, seed=1):
+    """stand-in for the cage family (DNA electrophoresis): ~per_row entries per row, most of them within a band around the
+    diagonal, the rest uniformly random; values U(0,1); diagonal present."""
+    m = int(n * (per_row - 1))
+    e = np.arange(m, dtype=np.uint64)
+    s = np.uint64(seed) << np.uint64(44)
+    r = (splitmix64(s + e * np.uint64(4)) % np.uint64(n)).astype(np.int64)
+    u = uniform01(s + e * np.uint64(4) + np.uint64(1))
+    off = (splitmix64(s + e * np.uint64(4) + np.uint64(2)) % np.uint64(2 * half_bw + 1)).astype(np.int64) - half_bw
+    far = (splitmix64(s + e * np.uint64(4) + np.uint64(3)) % np.uint64(n)).astype(np.int64)
+    c = np.where(u < local_frac, np.clip(r + off, 0, n - 1), far)
+    v = uniform01(s + e * np.uint64(4) + np.uint64(1) + (np.uint64(1) << np.uint64(40)))
+    d = np.arange(n, dtype=np.int64)
+    rows, cols, vals = _merge(n, n, np.concatenate([r, d]), np.concatenate([c, d]), np.concatenate([v, np.ones(n)]))
+    return n, n, rows, cols, vals
+
+
 def random_coo(n_rows, n_cols, nnz, seed=1, lo=-1.0, hi=1.0, integer=False):
     """nnz random coordinates (duplicates merged), for ragged / empty-row edge cases."""
     e = np.arange(nnz, dtype=np.uint64)

@@ -123,13 +123,20 @@ def check_spmv(oracle, bmsp, nr, nc, r, c, v, xkind="cusp"):
     y64 = S @ x.astype(np.float64)
     bound = 1e-5 * (abs(S) @ np.abs(x.astype(np.float64))) + 1e-30
     dx = bmsp.DeviceArray.from_host(x)
-    for batched in (False, True):
+    first = None
+    for variant in (0, 0, 1, 2):  # sweep (twice: arrival counters must reset, result bitwise reproducible), batched, row-group
         du = bmsp.DeviceArray(nr, np.float32)
         assert bmsp.lib().bmsp_memset(du.ptr, 0xFF, nr * 4) == 0  # NaN poison: every row must be written
-        y = bmsp.spmv(got, dx, du, batched=batched).to_host()
+        bmsp.check(bmsp.lib().bmsp_spmv(got.h, dx.ptr, du.ptr, variant, None))
+        y = du.to_host()
         assert np.all(np.isfinite(y))
         assert np.all(np.abs(y - y_ref) <= bound + 1e-5 * np.abs(y_ref)), np.max(np.abs(y - y_ref))
         assert np.all(np.abs(y - y64) <= 2 * bound + 1e-5 * np.abs(y64))
+        if variant == 0:
+            if first is None:
+                first = y
+            else:
+                np.testing.assert_array_equal(first.view(np.uint32), y.view(np.uint32))
     return y_ref
 
 
@@ -147,7 +154,7 @@ def test_spmv_fixtures(oracle, bmsp, path):
     check_spmv(oracle, bmsp, coo.num_rows, coo.num_cols, coo.rows, coo.cols, coo.vals)  # includes empty rows / ragged edges
 
 
-@pytest.mark.parametrize("case", ["banded", "rmat", "ragged", "empty_rows", "wide"])
+@pytest.mark.parametrize("case", ["banded", "rmat", "ragged", "empty_rows", "wide", "hub", "one_block_rows", "gap"])
 def test_spmv_synthetic(oracle, bmsp, case):
     from pybmsp import gen
     if case == "banded":
@@ -158,8 +165,24 @@ def test_spmv_synthetic(oracle, bmsp, case):
         nr, nc, r, c, v = gen.random_coo(1003, 517, 20000, seed=4)
     elif case == "empty_rows":
         nr, nc, r, c, v = gen.random_coo(4000, 4000, 300, seed=5)  # most block-rows empty (reference bug)
+    elif case == "wide":
+        nr, nc, r, c, v = gen.random_coo(16, 50000, 60000, seed=6)  # two block-rows with thousands of tiles (long-row items)
+    elif case == "hub":
+        # short rows, then a hub block-row of ~3000 tiles in the middle of a 64-row window, then short rows again
+        _, _, r1, c1, v1 = gen.random_coo(2000, 30000, 6000, seed=7)
+        _, _, r2, c2, v2 = gen.random_coo(8, 30000, 9000, seed=8)
+        nr, nc = 2000, 30000
+        r, c, v = np.concatenate([r1, r2 + 1000]), np.concatenate([c1, c2]), np.concatenate([v1, v2])
+        _, idx = np.unique(r.astype(np.int64) * nc + c, return_index=True)
+        r, c, v = r[idx], c[idx], v[idx]
+    elif case == "one_block_rows":
+        n = 3000  # one tile per block-row: items are bounded by the 64-row window, not by the tile budget
+        r = np.arange(n); c = (np.arange(n) * 7) % n; v = np.linspace(-1, 1, n)
+        nr, nc = n, n
     else:
-        nr, nc, r, c, v = gen.random_coo(16, 50000, 60000, seed=6)  # two block-rows with thousands of tiles
+        # blocks only at the very beginning and the very end: huge runs of empty block-rows between items
+        nr, nc = 100000, 100000
+        r = np.array([0, 3, 9, 99990, 99999]); c = np.array([5, 99999, 0, 17, 99999]); v = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
     check_spmv(oracle, bmsp, nr, nc, r, c, v)
     check_spmv(oracle, bmsp, nr, nc, r, c, v, "ones")
 
@@ -172,9 +195,10 @@ def test_spmv_linearity_large(bmsp):
     A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
     rowsum = np.bincount(r, weights=np.asarray(v, np.float32).astype(np.float64), minlength=n)
     ones = bmsp.DeviceArray.from_host(np.ones(n, np.float32))
-    for batched in (False, True):
-        u = bmsp.spmv(A, ones, batched=batched).to_host()
-        np.testing.assert_allclose(u, rowsum, rtol=1e-5, atol=1e-6)
+    for variant in (0, 1):
+        du = bmsp.DeviceArray(n, np.float32)
+        bmsp.check(bmsp.lib().bmsp_spmv(A.h, ones.ptr, du.ptr, variant, None))
+        np.testing.assert_allclose(du.to_host(), rowsum, rtol=1e-5, atol=1e-6)
     x = gen.spmv_x(n, "cusp")
     y = ((np.arange(n) % 7) - 3).astype(np.float32)
     ax = bmsp.spmv(A, bmsp.DeviceArray.from_host(x)).to_host().astype(np.float64)
