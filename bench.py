@@ -81,7 +81,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BMSP_FORCE_DIST") == "1"  # the latter rehearses the N>1 plumbing with one rank
+    if use_dist:
         import torch  # before the bmsp library: one HIP runtime for both (see pybmsp docstring)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -171,13 +172,13 @@ def main():
            "roofline": roofline}
 
     # ---------------- SpGEMM (configs[2], configs[3]) on rank 0 / single GPU ----------------
-    if not args.skip_spgemm and world == 1:
+    if not args.skip_spgemm and not use_dist:
         out["spgemm"] = bench_spgemm(B, gen, np, args)
-    if world > 1 and not args.skip_spgemm:
+    if use_dist and not args.skip_spgemm:
         out["spgemm_sharded"] = bench_spgemm_sharded(B, gen, np, torch, dist, rank, world)
 
     # ---------------- CPU baseline (cusp::multiply restatement) on rank 0, N = 1 only ----------------
-    if rank == 0 and world == 1 and not args.skip_cpu:
+    if rank == 0 and not use_dist and not args.skip_cpu:
         out["cpu_baseline"] = cpu_baseline(wl, eff_bytes, args)
 
     if rank == 0:

@@ -1,0 +1,103 @@
+"""CPU tests of the N > 1 path (world_size 2, gloo): the row-panel decomposition of the SpGEMM and the allgatherv of the
+C panels.  The panel products themselves come from the oracle here (no GPU in this container); what is under test is the
+host logic that runs unchanged on the GPU ranks: panel bounds, the padded all-gather exchange (pybmsp.shard.allgatherv)
+and the offset re-basing of the concatenation."""
+import os
+import socket
+import sys
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _balanced_bounds(work_per_row, parts):
+    """host mirror of bmsp_partition_rows: first block-row whose cumulative work reaches p/parts of the total."""
+    cum = np.concatenate([[0], np.cumsum(work_per_row)])
+    total = int(cum[-1])
+    bounds = [0]
+    r = 0
+    for p in range(1, parts):
+        target = total * p // parts
+        while r < len(work_per_row) and cum[r] < target:
+            r += 1
+        bounds.append(max(r, bounds[-1]))
+    bounds.append(len(work_per_row))
+    return bounds
+
+
+def _worker(rank, world, port, out_dir):
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(repo, "bmsparse-spgemm-spmv_amd"))
+    sys.path.insert(0, os.path.join(repo, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import oracle as O
+    from pybmsp import gen, shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, _, r, c, v = gen.rmat(9, 6, seed=3)
+    A = O.bmsp_from_coo(O.Coo(n, n, r, c, v), O.F32, False)
+    Bt = O.bmsp_from_coo(O.Coo(n, n, r, c, v), O.F32, True)
+    whole, _ = O.spgemm(A, Bt)
+    # candidate-task count per block-row of A = sum over its blocks of the blocks in B's matching block-row
+    nbr = (n + 7) // 8
+    b_rows = (Bt.keys >> np.uint64(32)).astype(np.int64)
+    b_per_row = np.bincount(b_rows, minlength=nbr)
+    a_rows = (A.keys >> np.uint64(32)).astype(np.int64)
+    a_cols = (A.keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    work = np.bincount(a_rows, weights=b_per_row[a_cols], minlength=nbr).astype(np.int64)
+    bounds = _balanced_bounds(work, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    # this rank's panel of A (block-rows [lo, hi)) as its own matrix with global keys
+    sel = (a_rows >= lo) & (a_rows < hi)
+    first = int(np.argmax(sel)) if sel.any() else 0
+    cnt = int(sel.sum())
+    o0 = int(A.offsets[first]) if cnt else 0
+    o1 = int(A.offsets[first + cnt]) if cnt else 0
+    panel = O.Bmsp(n, n, O.F32, 0, A.keys[sel], A.bmps[sel], A.offsets[first:first + cnt + 1] - np.uint64(o0), A.values[o0:o1])
+    Cp, st = O.spgemm(panel, Bt)
+    ints = torch.from_numpy(np.concatenate([Cp.keys, Cp.bmps, Cp.offsets]).astype(np.int64))
+    vals = torch.from_numpy(Cp.values.astype(np.float32))
+    gathered, nbytes = shard.allgatherv([ints, vals], dist, torch)
+    panels = []
+    for g in gathered:
+        nb = (g[0].numel() - 1) // 3
+        a = g[0].numpy().astype(np.uint64)
+        panels.append((a[:nb], a[nb:2 * nb], a[2 * nb:], g[1].numpy()))
+    keys, bmps, offs, values = shard.concat_host(panels)
+    ok = (np.array_equal(keys, whole.keys) and np.array_equal(bmps, whole.bmps) and np.array_equal(offs, whole.offsets)
+          and np.array_equal(values.astype(np.float64), whole.values))
+    sizes = [int(p[0].size) for p in panels]
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("%d %d %s %d\n" % (int(ok), nbytes, ",".join(map(str, sizes)), int(work[lo:hi].sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_spgemm_exchange_world2(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [open(tmp_path / ("rank%d.txt" % r)).read().split() for r in range(2)]
+    assert all(r[0] == "1" for r in res), res            # every rank reassembled exactly the whole product
+    assert res[0][1] == res[1][1] and int(res[0][1]) > 0  # same gathered byte count on both ranks
+    assert res[0][2] == res[1][2]
+    w0, w1 = int(res[0][3]), int(res[1][3])
+    assert abs(w0 - w1) <= 0.35 * (w0 + w1)              # panels balanced by candidate-task count
+
+
+def test_balanced_bounds_properties():
+    rng = np.random.default_rng(0)
+    work = (rng.pareto(1.2, 1000) * 10).astype(np.int64)
+    for parts in (1, 2, 3, 8):
+        b = _balanced_bounds(work, parts)
+        assert b[0] == 0 and b[-1] == 1000 and all(x <= y for x, y in zip(b, b[1:]))
+        loads = [int(work[b[i]:b[i + 1]].sum()) for i in range(parts)]
+        assert max(loads) <= work.sum() / parts + work.max()

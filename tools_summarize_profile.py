@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Condenses a tools_profile.sh output directory (gpurun_out/<name>) into profiles/<tag>_*.{csv,md} (tracked)."""
+import csv, glob, collections, os, shutil, sys
+
+src, tag, kern = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "spmv_sweep")
+os.makedirs("profiles", exist_ok=True)
+stats = glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))
+lines = ["# rocprofv3 summary `%s` (source: %s)" % (tag, src), "",
+         "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --skip-cpu --skip-spgemm --steps 100 --warmup 10`"
+         " and, in separate runs, `rocprofv3 --pmc <counters>` with the same command.", ""]
+if stats:
+    shutil.copy(stats[0], "profiles/%s_kernel_stats.csv" % tag)
+    lines += ["## kernel-trace --stats (top kernels)", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
+    for i, row in enumerate(csv.DictReader(open(stats[0]))):
+        if i >= 8: break
+        lines.append("| %s | %s | %.0f | %s | %s | %s |" % (row["Name"].split("(")[0][-70:], row["Calls"], float(row["AverageNs"]), row["MinNs"], row["MaxNs"], row["Percentage"]))
+lines += ["", "## PMC counters of `%s` (average per dispatch)" % kern, "", "| pass | counter | value |", "|---|---|---|"]
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d): continue
+    f = glob.glob(os.path.join(d, "*/*_counter_collection.csv"))
+    if not f: continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for row in csv.DictReader(open(f[0])):
+        if kern not in row["Kernel_Name"]: continue
+        a = agg[row["Counter_Name"]]; a[0] += 1; a[1] += float(row["Counter_Value"])
+    for c, (n, s) in sorted(agg.items()):
+        lines.append("| %s | %s | %.1f |" % (os.path.basename(d), c, s / n))
+lines += ["", "Notes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads "
+          "(MI355X_MICROARCH.md, HBM section) -- the correction factor for this kernel's 8-byte-per-lane streams and 4-byte gathers is "
+          "uncalibrated, so `traffic` lies between FETCH_SIZE and 2 x FETCH_SIZE.", ""]
+open("profiles/%s_summary.md" % tag, "w").write("\n".join(lines))
+print("\n".join(lines))
