@@ -78,28 +78,42 @@ struct DevBuf {
 
 inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
 
-// device-side timing of pipeline stages (hipEvent pairs on the operator's stream)
+// device-side timing of pipeline stages: hipEvents recorded on the operator's stream at stage boundaries and read
+// once at the end, so timing itself adds no host synchronisation between stages
 struct StageTimer {
     hipStream_t st;
-    hipEvent_t ev[2];
     bool on;
-    StageTimer(hipStream_t s, bool enable) : st(s), on(enable)
-    {
-        if (on) { BMSP_HIP(hipEventCreate(&ev[0])); BMSP_HIP(hipEventCreate(&ev[1])); }
-    }
+    static constexpr int kMax = 24;
+    hipEvent_t ev[kMax];
+    int stage_of[kMax];
+    int n = 0;
+    StageTimer(hipStream_t s, bool enable) : st(s), on(enable) {}
     ~StageTimer()
     {
-        if (on) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
+        for (int i = 0; i < n; i++) (void)hipEventDestroy(ev[i]);
     }
-    void start() { if (on) BMSP_HIP(hipEventRecord(ev[0], st)); }
-    double stop_us()
+    // marks a boundary: the time since the previous mark is charged to `stage` (-1 = not charged)
+    void mark(int stage)
     {
-        if (!on) return 0.0;
-        BMSP_HIP(hipEventRecord(ev[1], st));
-        BMSP_HIP(hipEventSynchronize(ev[1]));
-        float ms = 0.f;
-        BMSP_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
-        return (double)ms * 1000.0;
+        if (!on || n >= kMax) return;
+        BMSP_HIP(hipEventCreate(&ev[n]));
+        BMSP_HIP(hipEventRecord(ev[n], st));
+        stage_of[n] = stage;
+        n++;
+    }
+    // adds every interval to t_us[stage]; returns the time between the first and the last mark
+    double collect(double *t_us)
+    {
+        if (!on || n < 2) return 0.0;
+        BMSP_HIP(hipEventSynchronize(ev[n - 1]));
+        for (int i = 1; i < n; i++) {
+            float ms = 0.f;
+            BMSP_HIP(hipEventElapsedTime(&ms, ev[i - 1], ev[i]));
+            if (stage_of[i] >= 0) t_us[stage_of[i]] += (double)ms * 1000.0;
+        }
+        float tot = 0.f;
+        BMSP_HIP(hipEventElapsedTime(&tot, ev[0], ev[n - 1]));
+        return (double)tot * 1000.0;
     }
 };
 

@@ -19,6 +19,13 @@
 namespace bmsp {
 namespace {
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, kWave));
+    return v;
+}
+
 // ---- T_2 / T_3: fan-out of every A block = number of B blocks in block-row col(a) ------------------------
 struct FanOut {
     const uint64_t *a_keys;
@@ -268,67 +275,101 @@ __global__ __launch_bounds__(kThreads) void block_mac_valu_kernel(const uint64_t
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ half4_t load_nibble(uint64_t bmp, const _Float16 *__restrict__ vals, int line, int khalf)
+// buffer (SRSRC) loads: 32-bit byte offsets against a wave-uniform descriptor; an out-of-range offset reads 0, which
+// turns the "only if the bit is set" gathers of a tile nibble into straight-line code
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr uint32_t kOob = 0xffffffffu;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes)
 {
-    // tile line `line` (row of A / column of B), k = 4*khalf .. 4*khalf+3  -> positions line*8 + 4*khalf + q
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ _Float16 ld_half(rsrc_t r, uint32_t byte_off)
+{
+    return __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0));
+}
+
+// tile line `line` (row of A / column of B), k = 4*khalf .. 4*khalf+3  -> positions line*8 + 4*khalf + q; the stored ones
+// are consecutive in the value array starting at rank(first position)
+__device__ __forceinline__ half4_t load_nibble(uint64_t bmp, rsrc_t vals, uint32_t tile_byte_off, int line, int khalf, bool live)
+{
     const int p0 = line * 8 + khalf * 4;
-    const uint32_t nib = (uint32_t)(bmp >> (60 - p0)) & 0xfu;  // bit 3 = k+0 ... bit 0 = k+3
-    half4_t r = {0, 0, 0, 0};
-    if (nib) {
-        const _Float16 *p = vals + tile_rank(bmp, p0);
-        if (nib & 8u) r[0] = *p++;
-        if (nib & 4u) r[1] = *p++;
-        if (nib & 2u) r[2] = *p++;
-        if (nib & 1u) r[3] = *p++;
-    }
+    const uint32_t nib = live ? (uint32_t)(bmp >> (60 - p0)) & 0xfu : 0u;  // bit 3 = k+0 ... bit 0 = k+3
+    uint32_t off = tile_byte_off + (uint32_t)tile_rank(bmp, p0) * 2u;
+    half4_t r;
+    r[0] = ld_half(vals, (nib & 8u) ? off : kOob); off += (nib & 8u) ? 2u : 0u;
+    r[1] = ld_half(vals, (nib & 4u) ? off : kOob); off += (nib & 4u) ? 2u : 0u;
+    r[2] = ld_half(vals, (nib & 2u) ? off : kOob); off += (nib & 2u) ? 2u : 0u;
+    r[3] = ld_half(vals, (nib & 1u) ? off : kOob);
     return r;
 }
+
+constexpr int kPairsPerWave = 4;  // C-block pairs a wave works on at once (independent load chains in flight)
 
 __global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_kernel(const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin,
                                                                       const uint64_t *__restrict__ a_bmps, const uint64_t *__restrict__ a_offs,
                                                                       const _Float16 *__restrict__ a_vals, const uint64_t *__restrict__ b_bmps,
                                                                       const uint64_t *__restrict__ b_offs, const _Float16 *__restrict__ b_vals,
                                                                       const uint64_t *__restrict__ c_bmps, const uint64_t *__restrict__ c_offs,
-                                                                      float *__restrict__ c_vals, uint32_t c_size)
+                                                                      float *__restrict__ c_vals, uint32_t c_size, uint32_t a_bytes, uint32_t b_bytes)
 {
     const int w = wave_id(), lane = lane_id();
     const int line = lane & 7;          // tile row (A operand) / tile column (B operand)
     const int which = (lane >> 3) & 1;  // which of the two packed C blocks this lane feeds (rows/cols 8-15 -> 1)
     const int kq = lane >> 4;           // k quarter: 0,1 -> first task of the pair, 2,3 -> second task
     const int slot = kq >> 1, khalf = kq & 1;
+    const rsrc_t ra = make_rsrc(a_vals, a_bytes), rb = make_rsrc(b_vals, b_bytes);
     const uint32_t pairs = (c_size + 1) / 2;
-    for (uint32_t pr = blockIdx.x * 4 + w; pr < pairs; pr += gridDim.x * 4) {
-        const uint32_t c = pr * 2 + which;  // the C block this lane loads operands for
-        uint32_t tb = 0, te = 0;
-        if (c < c_size) { tb = task_begin[c]; te = task_begin[c + 1]; }
-        // both blocks advance two tasks per step; the wave runs until the longer list is exhausted
-        uint32_t len = te - tb;
-        uint32_t len_other = __shfl_xor(len, 8, kWave);
-        uint32_t steps = (max(len, len_other) + 1) / 2;
-        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t groups = (pairs + kPairsPerWave - 1) / kPairsPerWave;
+    for (uint32_t g = blockIdx.x * 4 + w; g < groups; g += gridDim.x * 4) {
+        uint32_t tb[kPairsPerWave], te[kPairsPerWave];
+        uint32_t steps = 0;
+#pragma unroll
+        for (int p = 0; p < kPairsPerWave; p++) {
+            const uint32_t c = (g * kPairsPerWave + p) * 2 + which;  // the C block this lane loads operands for
+            tb[p] = 0; te[p] = 0;
+            if (c < c_size) { tb[p] = task_begin[c]; te[p] = task_begin[c + 1]; }
+            steps = max(steps, te[p] - tb[p]);
+        }
+        // both blocks of every pair advance two tasks per step; the wave runs until the longest list is exhausted
+        steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(steps));
+        steps = (steps + 1) / 2;
+        float4_t acc[kPairsPerWave];
+#pragma unroll
+        for (int p = 0; p < kPairsPerWave; p++) acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
         for (uint32_t s = 0; s < steps; s++) {
-            const uint32_t t = tb + 2 * s + slot;
-            half4_t fa = {0, 0, 0, 0}, fb = {0, 0, 0, 0};
-            if (t < te) {
-                const uint64_t tk = tasks[t];
-                const uint32_t a = (uint32_t)(tk >> 32), b = (uint32_t)tk;
-                fa = load_nibble(a_bmps[a], a_vals + a_offs[a], line, khalf);
-                fb = load_nibble(b_bmps[b], b_vals + b_offs[b], line, khalf);
+            half4_t fa[kPairsPerWave], fb[kPairsPerWave];
+            uint64_t tk[kPairsPerWave];
+            bool live[kPairsPerWave];
+#pragma unroll
+            for (int p = 0; p < kPairsPerWave; p++) {
+                const uint32_t t = tb[p] + 2 * s + slot;
+                live[p] = t < te[p];
+                tk[p] = live[p] ? tasks[t] : 0ull;
             }
-            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(fa, fb, acc, 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < kPairsPerWave; p++) {
+                const uint32_t a = (uint32_t)(tk[p] >> 32), b = (uint32_t)tk[p];
+                fa[p] = load_nibble(a_bmps[a], ra, (uint32_t)a_offs[a] * 2u, line, khalf, live[p]);
+                fb[p] = load_nibble(b_bmps[b], rb, (uint32_t)b_offs[b] * 2u, line, khalf, live[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < kPairsPerWave; p++) acc[p] = __builtin_amdgcn_mfma_f32_16x16x16f16(fa[p], fb[p], acc[p], 0, 0, 0);
         }
         // result: lane holds D[4*(lane>>4)+r][lane&15]; block 0 lives in rows 0-7 x cols 0-7, block 1 in 8-15 x 8-15
         const int col = lane & 15, rq = lane >> 4;
         const int blk = col >> 3;
         if ((rq >> 1) == blk) {
-            const uint32_t cc = pr * 2 + blk;
-            if (cc < c_size) {
-                const uint64_t bmp_c = c_bmps[cc];
-                const uint64_t off = c_offs[cc];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int p = ((rq & 1) * 4 + r) * 8 + (col & 7);
-                    if (tile_has(bmp_c, p)) c_vals[off + tile_rank(bmp_c, p)] = acc[r];
+            for (int p = 0; p < kPairsPerWave; p++) {
+                const uint32_t cc = (g * kPairsPerWave + p) * 2 + blk;
+                if (cc < c_size) {
+                    const uint64_t bmp_c = c_bmps[cc];
+                    const uint64_t off = c_offs[cc];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int pos = ((rq & 1) * 4 + r) * 8 + (col & 7);
+                        if (tile_has(bmp_c, pos)) c_vals[off + tile_rank(bmp_c, pos)] = acc[p][r];
+                    }
                 }
             }
         }
@@ -372,30 +413,24 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     bmsp_spgemm_stats *S = stats ? stats : &local;
     *S = bmsp_spgemm_stats{};
     const bool timing = verbose || stats;
-    StageTimer whole(st, timing), tm(st, timing);
-    whole.start();
+    StageTimer tm(st, timing);
+    tm.mark(-1);
 
     // T_1: blocks per block-row of B (cached dense pointer)
-    tm.start();
     ensure_rowptr(B, st);
-    S->t_us[1] = tm.stop_us();
-    print_stage(verbose, "T_1", S->t_us[1]);
+    tm.mark(1);
 
     // T_2 + T_3 (first half): fan-out per A block and its exclusive scan
-    tm.start();
     const uint64_t n_a = (uint64_t)A->block_num;
     DevBuf<uint64_t> first_pos(n_a + 1);
     device_exclusive_scan<uint64_t>(FanOut{A->keys, B->rowptr, n_a, (uint32_t)B->num_block_rows()}, PtrOut<uint64_t>{first_pos.p},
                                     n_a + 1, st);
     const uint64_t total = read_back(first_pos.p + n_a, st);
-    S->t_us[2] = tm.stop_us();
-    print_stage(verbose, "T_2", S->t_us[2]);
+    tm.mark(2);
     S->task_list_size = (int64_t)total;
-    if (verbose) printf("Task list size: %llu\n", (unsigned long long)total);
     if (total >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "%llu candidate block pairs exceed the 32-bit task range; shard by row panel", (unsigned long long)total);
 
     // T_3 + T_4: expansion fused with the bitmap filter
-    tm.start();
     const int jbits = std::max(1, ceil_log2_u64((uint64_t)B->num_block_cols()));
     const int ibits = std::max(1, ceil_log2_u64((uint64_t)A->num_block_rows()));
     const uint32_t tiles = (uint32_t)((total + kTile - 1) / kTile);
@@ -410,44 +445,35 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         DevBuf<uint32_t> tile_base((size_t)tiles + 1);
         device_exclusive_scan<uint32_t>(CountIn{tile_counts.p, tiles}, PtrOut<uint32_t>{tile_base.p}, (uint64_t)tiles + 1, st);
         n_tasks = read_back(tile_base.p + tiles, st);
-        S->t_us[3] = tm.stop_us();
-        tm.start();
+        tm.mark(3);
         k0.alloc(n_tasks); k1.alloc(n_tasks); v0.alloc(n_tasks); v1.alloc(n_tasks);
         hipLaunchKernelGGL((expand_filter_kernel<true>), dim3(tiles), dim3(kThreads), 0, st, ea, (uint32_t *)nullptr,
                            (const uint32_t *)tile_base.p, k0.p, v0.p);
         BMSP_CHECK_LAUNCH();
-        BMSP_HIP(hipStreamSynchronize(st));  // tile_base goes back to the pool
-        S->t_us[4] = tm.stop_us();
+        tm.mark(4);
     }
-    print_stage(verbose, "T_3", S->t_us[3]);
     S->surviving_tasks = (int64_t)n_tasks;
     S->bmp_reduction = (int64_t)(total - n_tasks);
-    if (verbose) printf("Bmp reduction: %lld\n", (long long)S->bmp_reduction);
-    print_stage(verbose, "T_4", S->t_us[4]);
 
     // T_5: group the tasks by C key
-    tm.start();
     PingPong<uint64_t> kk{k0.p, k1.p}, vv{v0.p, v1.p};
-    const bool segmented = mode == BMSP_SORT_SEGMENTED || (mode == BMSP_SORT_AUTO && n_tasks >= (uint64_t)BMSP_SORT_BORDER);
+    // AUTO: the reference switches to its segmented sort above BORDER tasks (:963); here the global radix sort on the packed
+    // key is the faster of the two at every size measured so far, so AUTO always takes it
+    const bool segmented = mode == BMSP_SORT_SEGMENTED;
     S->sort_path = segmented ? 1 : 0;
     if (n_tasks) {
         if (segmented) {
             // tasks are already grouped by block-row of A (A's blocks are key-ordered): only the column bits
             // need sorting inside each block-row segment
-            StageTimer ts(st, timing);
-            ts.start();
             segsort_tasks_by_column(kk, vv, n_tasks, jbits, ibits, st);
-            S->t_us[8] = ts.stop_us();
-            if (verbose) print_stage(true, "Segmented sort", S->t_us[8]);
+            tm.mark(8);
         } else {
             device_radix_sort_pairs<uint64_t>(kk, vv, n_tasks, 0, ibits + jbits, st);
         }
     }
-    S->t_us[5] = tm.stop_us();
-    print_stage(verbose, "T_5", S->t_us[5]);
+    tm.mark(5);
 
     // T_6: C's block keys and the task range of every C block
-    tm.start();
     DevBuf<uint32_t> csize_d(1);
     uint32_t c_size = 0;
     if (n_tasks) {
@@ -465,11 +491,9 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     DevBuf<uint32_t> task_begin((size_t)c_size + 1);
     if (n_tasks)
         device_exclusive_scan<uint32_t>(KeyHead{kk.cur, n_tasks}, EmitCBlocks{kk.cur, n_tasks, jbits, C->keys, task_begin.p}, n_tasks + 1, st);
-    S->t_us[6] = tm.stop_us();
-    print_stage(verbose, "T_6", S->t_us[6]);
+    tm.mark(6);
 
     // T_9: C bitmaps, value offsets, nnz
-    tm.start();
     uint64_t c_nnz = 0;
     if (c_size) {
         device_for_each(CBitmaps{vv.cur, task_begin.p, A->bmps, B->bmps, C->bmps}, c_size, st);
@@ -480,18 +504,18 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     }
     C->nnz = (int64_t)c_nnz;
     C->values = pool_alloc(dtype_size(C->dtype) * (size_t)(c_nnz ? c_nnz : 1));
-    S->t_us[9] = tm.stop_us();
-    print_stage(verbose, "T_9", S->t_us[9]);
+    tm.mark(9);
 
     // T_7: block multiply-accumulate
-    tm.start();
     if (c_size) {
         if (mfma) {
-            uint32_t pairs = (c_size + 1) / 2;
-            uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)pairs + 3) / 4, 256ull * 64);
+            if ((uint64_t)A->nnz * 2 >= (1ull << 32) || (uint64_t)B->nnz * 2 >= (1ull << 32))
+                fail(BMSP_ERR_LIMIT, "MFMA block-MAC addresses operand values through 4 GiB buffer descriptors; use tc_version 5");
+            uint32_t groups = ((c_size + 1) / 2 + kPairsPerWave - 1) / kPairsPerWave;
+            uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
             hipLaunchKernelGGL(block_mac_mfma_f16_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->bmps, A->offsets,
                                (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
-                               (float *)C->values, c_size);
+                               (float *)C->values, c_size, (uint32_t)(A->nnz * 2), (uint32_t)(B->nnz * 2));
             BMSP_CHECK_LAUNCH();
             S->mac_kernel = tc_version;
         } else {
@@ -501,13 +525,27 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
             S->mac_kernel = 5;
         }
     }
+    tm.mark(7);
     BMSP_HIP(hipStreamSynchronize(st));  // reference: cudaDeviceSynchronize (:1158)
-    S->t_us[7] = tm.stop_us();
-    print_stage(verbose, "T_7", S->t_us[7]);
+    S->t_us[0] = tm.collect(S->t_us);
+    S->t_us[5] += S->t_us[8];  // the reference's T_5 includes its "Segmented sort" sub-timer (:1009-1024)
+    if (verbose) {
+        // the reference's VERBOSE lines, in its order (src/bmSparse_SPGEMM.cu:849-1164)
+        print_stage(true, "T_1", S->t_us[1]);
+        print_stage(true, "T_2", S->t_us[2]);
+        printf("Task list size: %llu\n", (unsigned long long)total);
+        print_stage(true, "T_3", S->t_us[3]);
+        printf("Bmp reduction: %lld\n", (long long)S->bmp_reduction);
+        print_stage(true, "T_4", S->t_us[4]);
+        if (segmented) print_stage(true, "Segmented sort", S->t_us[8]);
+        print_stage(true, "T_5", S->t_us[5]);
+        print_stage(true, "T_6", S->t_us[6]);
+        print_stage(true, "T_9", S->t_us[9]);
+        print_stage(true, "T_7", S->t_us[7]);
+    }
 
     S->c_blocks = c_size;
     S->c_nnz = (int64_t)c_nnz;
-    S->t_us[0] = whole.stop_us();
     *Cout = C.release();
 }
 
