@@ -157,8 +157,15 @@ def main():
 
     kern_ms = dev_ms / args.steps  # HIP events on the launch stream, over the timed region
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    # HBM traffic from the PMC counters (separate rocprofv3 passes, summarised under profiles/); only quoted for the workload
+    # it was collected on
+    traffic = None
+    if "coo" in wl and not args.spmv_matrix and args.scale == 20 and args.edge_factor == 2.0:
+        import glob
+        for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_spmv_webbase_like_traffic.json"))):
+            traffic = json.load(open(f))["traffic_bytes_per_launch"]
     roofline = {"bound": "hbm", "kernel": "spmv_sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(kern_ms, 5)}
 
     out = {"metric": "bmSparse SpMV fp32 effective GB/s (CSR-convention bytes / time); SpGEMM GFLOP/s under `spgemm`",

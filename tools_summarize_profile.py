@@ -28,5 +28,23 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
 lines += ["", "Notes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads "
           "(MI355X_MICROARCH.md, HBM section) -- the correction factor for this kernel's 8-byte-per-lane streams and 4-byte gathers is "
           "uncalibrated, so `traffic` lies between FETCH_SIZE and 2 x FETCH_SIZE.", ""]
+# HBM traffic of the kernel per launch, corrected as MI355X_MICROARCH.md prescribes and as experiments/fetch_calib.hip confirms for
+# this kernel's access shapes (8-byte-per-lane streams and 4-byte gathers both count 64 B per 128-B request): 2 x FETCH_SIZE + WRITE_SIZE
+import json
+tot = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    f = glob.glob(os.path.join(d, "*/*_counter_collection.csv")) if os.path.isdir(d) else []
+    if not f: continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for row in csv.DictReader(open(f[0])):
+        if kern in row["Kernel_Name"]:
+            a = agg[row["Counter_Name"]]; a[0] += 1; a[1] += float(row["Counter_Value"])
+    for c, (n, sm) in agg.items(): tot[c] = sm / n
+if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+    tr = {"kernel": kern, "fetch_size_kib": tot["FETCH_SIZE"], "write_size_kib": tot["WRITE_SIZE"],
+          "traffic_bytes_per_launch": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024),
+          "method": "2*FETCH_SIZE + WRITE_SIZE (KiB), separate --pmc passes; factor 2 calibrated by experiments/fetch_calib.hip"}
+    json.dump(tr, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
+    lines += ["", "HBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE = %.1f MB" % (tr["traffic_bytes_per_launch"] / 1e6), ""]
 open("profiles/%s_summary.md" % tag, "w").write("\n".join(lines))
 print("\n".join(lines))
