@@ -10,6 +10,9 @@
 #include <algorithm>
 #include <cctype>
 #include <memory>
+#include <thread>
+#include <string>
+#include <cstdlib>
 #include <cerrno>
 #include <cstring>
 #include <fcntl.h>
@@ -56,10 +59,47 @@ inline bool parse_i64(const char *&s, const char *e, long long &out)
     out = neg ? -v : v;
     return true;
 }
+// decimal -> double.  Fast path (exactly rounded): at most 15 significant digits and |exponent| <= 22, so mantissa and
+// power of ten are both exact doubles and one multiplication / division rounds once.  Everything else goes to strtod.
 inline bool parse_f64(const char *&s, const char *e, double &out)
 {
     s = skip_ws(s, e);
     if (s >= e) return false;
+    {
+        static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+        const char *q = s;
+        bool neg = false;
+        if (q < e && (*q == '-' || *q == '+')) { neg = *q == '-'; q++; }
+        uint64_t mant = 0;
+        int digits = 0, frac = 0;
+        bool any = false, ok = true;
+        while (q < e && *q >= '0' && *q <= '9') { if (mant || *q != '0') digits++; mant = mant * 10 + (uint64_t)(*q - '0'); q++; any = true; if (digits > 15) ok = false; }
+        if (q < e && *q == '.') {
+            q++;
+            while (q < e && *q >= '0' && *q <= '9') { if (mant || *q != '0') digits++; mant = mant * 10 + (uint64_t)(*q - '0'); q++; frac++; any = true; if (digits > 15) ok = false; }
+        }
+        int ex = 0;
+        if (any && ok && q < e && (*q == 'e' || *q == 'E')) {
+            const char *r = q + 1;
+            bool eneg = false;
+            if (r < e && (*r == '-' || *r == '+')) { eneg = *r == '-'; r++; }
+            if (r < e && *r >= '0' && *r <= '9') {
+                int v = 0;
+                while (r < e && *r >= '0' && *r <= '9' && v < 10000) { v = v * 10 + (*r - '0'); r++; }
+                ex = eneg ? -v : v;
+                q = r;
+            } else ok = false;
+        }
+        const bool at_end = q >= e || *q == ' ' || *q == '\t' || *q == '\r' || *q == '\n';
+        const int e10 = ex - frac;
+        if (any && ok && at_end && e10 >= -22 && e10 <= 22) {
+            double v = (double)mant;
+            v = e10 < 0 ? v / p10[-e10] : v * p10[e10];
+            out = neg ? -v : v;
+            s = q;
+            return true;
+        }
+    }
     char buf[64];
     size_t k = 0;
     while (s + k < e && k < sizeof(buf) - 1 && !(s[k] == ' ' || s[k] == '\t' || s[k] == '\r' || s[k] == '\n')) {
@@ -134,22 +174,70 @@ void read_matrix_market(const std::string &path_in, HostCoo &out)
     if (nr > 0x7fffffffLL || nc > 0x7fffffffLL) fail(BMSP_ERR_LIMIT, "'%s': dimensions exceed int32", path.c_str());
     out.num_rows = (int)nr;
     out.num_cols = (int)nc;
-    size_t cap = (size_t)(sym ? 2 * nz : nz);
-    out.rows.clear(); out.cols.clear(); out.vals.clear();
-    out.rows.reserve(cap); out.cols.reserve(cap); out.vals.reserve(cap);
-    for (long long l = 0; l < nz; l++) {
-        long long r, c;
-        double v = 1.0, im;
-        if (!parse_i64(s, e, r) || !parse_i64(s, e, c))
-            fail(BMSP_ERR_IO, "'%s': unexpected end of file at entry %lld of %lld", path.c_str(), l, nz);
-        if (!pattern && !parse_f64(s, e, v)) fail(BMSP_ERR_IO, "'%s': missing value at entry %lld", path.c_str(), l);
-        if (cplx && !parse_f64(s, e, im)) fail(BMSP_ERR_IO, "'%s': missing imaginary part at entry %lld", path.c_str(), l);
-        if (r < 1 || c < 1 || r > nr || c > nc)
-            fail(BMSP_ERR_IO, "'%s': entry %lld has index (%lld,%lld) outside %lldx%lld", path.c_str(), l, r, c, nr, nc);
-        out.rows.push_back((int)(r - 1)); out.cols.push_back((int)(c - 1)); out.vals.push_back(v);
-        if (sym && r != c) {  // mirror off-diagonal entries (src/bmSpMatrix.cu:142-147)
-            out.rows.push_back((int)(c - 1)); out.cols.push_back((int)(r - 1)); out.vals.push_back(sym < 0 ? -v : v);
+    // body: nz entry lines, parsed by several host threads on line-aligned slices of the mapped file
+    const char *body = s;
+    unsigned hw = std::thread::hardware_concurrency();
+    try { hw = std::min<unsigned>(hw ? hw : 1u, (unsigned)std::max<long>(1, sysconf(_SC_NPROCESSORS_ONLN))); } catch (...) {}
+    size_t nthreads = std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)16, (size_t)((e - body) >> 20) + 1});
+    if (const char *env = getenv("BMSP_PARSE_THREADS")) nthreads = std::max(1, atoi(env));
+    struct Part { std::vector<int> r, c; std::vector<double> v; long long lines = 0; std::string err; };
+    std::vector<Part> parts(nthreads);
+    std::vector<const char *> cut(nthreads + 1);
+    cut[0] = body; cut[nthreads] = e;
+    for (size_t t = 1; t < nthreads; t++) {
+        const char *p = body + (size_t)(e - body) * t / nthreads;
+        while (p < e && *p != '\n') p++;
+        cut[t] = p < e ? p + 1 : e;
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    auto work = [&](size_t t) {
+        Part &P = parts[t];
+        const char *q = cut[t], *qe = cut[t + 1];
+        size_t guess = (size_t)(qe - q) / 12 + 16;
+        P.r.reserve(sym ? 2 * guess : guess); P.c.reserve(sym ? 2 * guess : guess); P.v.reserve(sym ? 2 * guess : guess);
+        char msg[160];
+        for (;;) {
+            q = skip_ws(q, qe);
+            if (q >= qe) break;
+            long long r, c;
+            double v = 1.0, im;
+            if (!parse_i64(q, qe, r) || !parse_i64(q, qe, c)) { P.err = "malformed entry line"; return; }
+            if (!pattern && !parse_f64(q, qe, v)) { P.err = "missing value"; return; }
+            if (cplx && !parse_f64(q, qe, im)) { P.err = "missing imaginary part"; return; }
+            if (r < 1 || c < 1 || r > nr || c > nc) {
+                snprintf(msg, sizeof msg, "index (%lld,%lld) outside %lldx%lld", r, c, nr, nc);
+                P.err = msg;
+                return;
+            }
+            P.lines++;
+            P.r.push_back((int)(r - 1)); P.c.push_back((int)(c - 1)); P.v.push_back(v);
+            if (sym && r != c) {  // mirror off-diagonal entries (src/bmSpMatrix.cu:142-147)
+                P.r.push_back((int)(c - 1)); P.c.push_back((int)(r - 1)); P.v.push_back(sym < 0 ? -v : v);
+            }
         }
+    };
+    if (nthreads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nthreads; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    long long lines = 0;
+    size_t total = 0;
+    for (auto &P : parts) {
+        if (!P.err.empty()) fail(BMSP_ERR_IO, "'%s': %s", path.c_str(), P.err.c_str());
+        lines += P.lines;
+        total += P.r.size();
+    }
+    if (lines < nz) fail(BMSP_ERR_IO, "'%s': unexpected end of file: %lld of %lld entries", path.c_str(), lines, nz);
+    if (lines > nz) fail(BMSP_ERR_IO, "'%s': %lld entry lines but the size line announces %lld", path.c_str(), lines, nz);
+    out.rows.resize(total); out.cols.resize(total); out.vals.resize(total);
+    size_t at = 0;
+    for (auto &P : parts) {
+        std::copy(P.r.begin(), P.r.end(), out.rows.begin() + at);
+        std::copy(P.c.begin(), P.c.end(), out.cols.begin() + at);
+        std::copy(P.v.begin(), P.v.end(), out.vals.begin() + at);
+        at += P.r.size();
     }
 }
 

@@ -414,22 +414,23 @@ int bmsp_csr_from_mtx(const char *path, bmsp_csr_t *out)
     HostCoo coo;
     read_matrix_market(path, coo);
     size_t n = coo.rows.size();
-    std::vector<size_t> perm(n);
-    std::iota(perm.begin(), perm.end(), (size_t)0);
-    // CUSP's reader sorts by (row, column) (cusp/io/detail/matrix_market.inl:295)
-    std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) {
-        return coo.rows[a] != coo.rows[b] ? coo.rows[a] < coo.rows[b] : coo.cols[a] < coo.cols[b];
-    });
     std::unique_ptr<bmsp_csr_s> m(new bmsp_csr_s());
     m->num_rows = coo.num_rows; m->num_cols = coo.num_cols;
     m->row_offsets.assign((size_t)coo.num_rows + 1, 0);
     m->cols.resize(n); m->vals.resize(n);
-    for (size_t i = 0; i < n; i++) {
-        m->row_offsets[(size_t)coo.rows[perm[i]] + 1]++;
-        m->cols[i] = coo.cols[perm[i]];
-        m->vals[i] = (float)coo.vals[perm[i]];
-    }
+    // CUSP's reader sorts by (row, column) (cusp/io/detail/matrix_market.inl:295): stable counting sort by row, then a
+    // stable sort by column inside each row
+    for (size_t i = 0; i < n; i++) m->row_offsets[(size_t)coo.rows[i] + 1]++;
     for (int r = 0; r < coo.num_rows; r++) m->row_offsets[(size_t)r + 1] += m->row_offsets[(size_t)r];
+    {
+        std::vector<int> fill(m->row_offsets.begin(), m->row_offsets.end() - 1);
+        std::vector<std::pair<int, float>> tmp(n);
+        for (size_t i = 0; i < n; i++) tmp[(size_t)fill[(size_t)coo.rows[i]]++] = std::make_pair(coo.cols[i], (float)coo.vals[i]);
+        for (int r = 0; r < coo.num_rows; r++)
+            std::stable_sort(tmp.begin() + m->row_offsets[(size_t)r], tmp.begin() + m->row_offsets[(size_t)r + 1],
+                             [](const std::pair<int, float> &a, const std::pair<int, float> &b) { return a.first < b.first; });
+        for (size_t i = 0; i < n; i++) { m->cols[i] = tmp[i].first; m->vals[i] = tmp[i].second; }
+    }
     *out = m.release();
     BMSP_API_END
 }

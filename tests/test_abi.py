@@ -70,3 +70,52 @@ def test_generators_are_deterministic():
     assert r.size == 100 * 7 - 2 * (1 + 2 + 3) and np.all(np.abs(r - c) <= 3) and np.all(np.abs(v) <= 1)
     # splitmix64 known answer (seed 0 first output of the reference implementation)
     assert int(gen.splitmix64(np.array([0], dtype=np.uint64))[0]) == 0xE220A8397B1DCDAF
+
+
+def _write_mtx(path, n, nnz, seed, banner="%%MatrixMarket matrix coordinate real general"):
+    rng = np.random.default_rng(seed)
+    r = rng.integers(1, n + 1, nnz)
+    c = rng.integers(1, n + 1, nnz)
+    # number shapes seen in SuiteSparse files: short decimals, 16-17 significant digits, exponents, integers, negatives
+    v = rng.standard_normal(nnz) * 10.0 ** rng.integers(-30, 30, nnz)
+    fmt = rng.integers(0, 5, nnz)
+    with open(path, "w") as f:
+        f.write(banner + "\n% comment\n%\n")
+        f.write("%d %d %d\n" % (n, n, nnz))
+        txt = []
+        for i in range(nnz):
+            s = ["%.3f" % (v[i] % 1000), "%.17g" % v[i], "%.15e" % v[i], "%d" % int(v[i] % 1000), "%r" % float(v[i])][fmt[i]]
+            txt.append("%d %d %s\n" % (r[i], c[i], s) if i % 7 else "  %d\t%d   %s \n" % (r[i], c[i], s))
+        f.write("".join(txt))
+    return r, c
+
+
+def test_parallel_parser_matches_python_float(bmsp, tmp_path, monkeypatch):
+    """the multi-threaded MatrixMarket reader (exact fast path + strtod fallback) against Python's float() on every token,
+    single-threaded and 7-threaded, via the host-only CSR entry point."""
+    path = str(tmp_path / "rand.mtx")
+    n, nnz = 5000, 200000
+    _write_mtx(path, n, nnz, 11)
+    toks = [l.split() for l in open(path).read().splitlines()[4:]]
+    rows = np.array([int(t[0]) - 1 for t in toks]); cols = np.array([int(t[1]) - 1 for t in toks])
+    vals = np.array([float(t[2]) for t in toks])
+    order = np.lexsort((cols, rows))  # stable (row, col) sort like the CUSP reader
+    with np.errstate(over="ignore"):
+        ref_vals = vals[order].astype(np.float32)
+    results = []
+    for threads in ("1", "7"):
+        monkeypatch.setenv("BMSP_PARSE_THREADS", threads)
+        nr, nc, ro, ci, v = bmsp.CSRMatrix.from_mtx(path).arrays()
+        assert (nr, nc, ci.size) == (n, n, nnz)
+        np.testing.assert_array_equal(ci, cols[order])
+        np.testing.assert_array_equal(v.view(np.uint32), ref_vals.view(np.uint32))
+        results.append((ro, ci, v))
+    np.testing.assert_array_equal(results[0][0], results[1][0])
+    # truncated and over-long bodies are errors, not silent garbage
+    lines = open(path).read().splitlines(True)
+    open(path, "w").write("".join(lines[:-5]))
+    with pytest.raises(bmsp.BmspError):
+        bmsp.CSRMatrix.from_mtx(path)
+    open(path, "w").write("".join(lines + ["1 1 1.0\n"]))
+    with pytest.raises(bmsp.BmspError):
+        bmsp.CSRMatrix.from_mtx(path)
