@@ -436,3 +436,51 @@ def test_row_panels_concat_equals_whole(oracle, bmsp):
         cat = bmsp.concat_panels(n, n, panels)
         for x, y in zip(cat.host_arrays(), whole.host_arrays()):
             np.testing.assert_array_equal(x, y)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# drop-in executables and batch scripts (boundary: argv + stdout contract)
+# ---------------------------------------------------------------------------------------------------------
+def test_cli_executables_and_batch_scripts(tmp_path):
+    import shutil
+    import subprocess
+    from conftest import REPO
+    folder = os.path.join(MTX, "real")
+    env = dict(os.environ, BMSP_PRINT_CHECKSUM="1")
+    out = subprocess.run([os.path.join(REPO, "bmsparse_spmv_float"), folder, "A_matrix", "A_matrix", "0"], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[0] == "A matrix: %s/A_matrix" % folder
+    assert lines[1].startswith("Parsing mtx files / Loading matrices from disk BMSP: ") and lines[1].endswith(" μs")
+    assert lines[2].strip() == "Running SpMV"
+    assert lines[3].startswith("Parsing mtx files / Loading matrix and vectors: ")
+    assert lines[4].startswith("bmSparse SpMV execution: ") and lines[4].endswith(" μs")
+    assert lines[5] == "u checksum: 109"  # sum of y = A*1
+    for seg, tc in (("0", "5"), ("1", "4")):
+        out = subprocess.run([os.path.join(REPO, "bmsparse_spgemm_float"), folder, "A_matrix", "B_matrix", seg, tc, "1"], capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stderr
+        text = out.stdout
+        labels = ["A matrix: ", "B matrix: ", "Parsing mtx files / Loading matrices from disk BMSP: ", "T_1: ", "T_2: ", "Task list size: 27",
+                  "T_3: ", "Bmp reduction: 0", "T_4: ", "T_5: ", "T_6: ", "T_9: ", "T_7: ", "Toda F: ", "bmSparse execution: ", "C blocks: 9", "C nnz: 255",
+                  "C checksum: 1070"]
+        pos = -1
+        for lab in labels:  # same labels, same order as the reference
+            nxt = text.find(lab, pos + 1)
+            assert nxt > pos, (lab, text)
+            pos = nxt
+        if seg == "1":
+            assert "Segmented sort: " in text
+    # usage errors: exit code 1 and the reference's usage line
+    out = subprocess.run([os.path.join(REPO, "bmsparse_spgemm_float"), folder], capture_output=True, text=True)
+    assert out.returncode == 1 and "./main MatrixFolder A_Matrix B_Matrix" in out.stdout
+    out = subprocess.run([os.path.join(REPO, "bmsparse_spmv_float"), folder, "missing", "missing", "0"], capture_output=True, text=True)
+    assert out.returncode == 2 and "cannot open" in out.stderr
+    # batch drivers: list file -> one run per line, output appended to *_out.txt
+    lst = tmp_path / "lista9.txt"
+    lst.write_text("A_matrix\nB_matrix\n")
+    for script, outfile, needle in (("spmv_run_batch.sh", "spmv_out.txt", "bmSparse SpMV execution"), ("spgemm_run_batch.sh", "spgemm_out.txt", "C nnz: 255")):
+        r = subprocess.run(["bash", os.path.join(REPO, script)], cwd=tmp_path, capture_output=True, text=True,
+                           env=dict(os.environ, folder=folder, list=str(lst)))
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.count("Working on") == 2
+        assert (tmp_path / outfile).read_text().count(needle) == 2
