@@ -41,8 +41,9 @@ struct Acc { using type = float; };
 template <>
 struct Acc<double> { using type = double; };
 
-constexpr uint32_t kItemTiles = 128;  // tile budget of an item (short items hold < 2x this, long-row items exactly this)
-constexpr uint32_t kItemRows = 64;    // block-rows per item window (u tile = 64 x 8 accumulators)
+constexpr uint32_t kItemTiles = 256;  // tile budget of an item (short items hold < 2x this, long-row items exactly this)
+constexpr uint32_t kBatch = 128;      // tiles a wave loads at once (two per lane)
+constexpr uint32_t kItemRows = 16;    // block-rows per item window (u tile = 16 x 8 accumulators)
 
 struct SweepItem {      // 32 bytes, read with scalar loads
     uint32_t row_begin, row_end;  // block-rows [row_begin, row_end)
@@ -183,7 +184,9 @@ struct Buf<double> {
 };
 
 constexpr int kSparseMax = 8;   // tiles with more stored values than this go to the wave-wide dense pass
+constexpr int kInlineSlots = 2; // stored values of a tile handled in the streaming loop; the rest of a tile waits in a queue
 constexpr int kDenseTrip = 8;   // dense tiles per trip of the wave-wide pass
+constexpr uint32_t kLeftCap = 64 + kBatch;  // leftover queue: flushed 64 tiles at a time, so every lane has work
 
 template <typename A>
 __device__ __forceinline__ void lds_add(A *p, A v)
@@ -206,16 +209,17 @@ __device__ __forceinline__ double row8_sum(double v)
     return v;
 }
 
-// the (up to kSparseMax) stored elements of one tile, handled by ONE lane: positions peeled off the top of the bitmap,
-// all value / x loads issued back to back, then the LDS adds (exec-masked: ds_add_f32 is priced per active lane)
-template <typename T, typename A>
-__device__ __forceinline__ void sparse_tile(uint64_t bm, uint32_t voff, uint32_t xbase, A *__restrict__ trow, rsrc_t rv, rsrc_t rx)
+// up to N stored elements of one tile, handled by ONE lane: positions peeled off the top of the bitmap, all value / x
+// loads issued back to back (absent ones point out of range and read 0), then the LDS adds (exec-masked).  Returns the
+// bitmap of the elements that are left.
+template <typename T, typename A, int N>
+__device__ __forceinline__ uint64_t peel_tile(uint64_t bm, uint32_t voff, uint32_t xbase, A *__restrict__ trow, rsrc_t rv, rsrc_t rx)
 {
-    A a[kSparseMax], xv[kSparseMax];
-    uint32_t pr[kSparseMax];
-    bool has[kSparseMax];
+    A a[N], xv[N];
+    uint32_t pr[N];
+    bool has[N];
 #pragma unroll
-    for (int j = 0; j < kSparseMax; j++) {
+    for (int j = 0; j < N; j++) {
         has[j] = bm != 0;
         const uint32_t p = (uint32_t)__clzll((long long)bm) & 63u;
         bm &= ~(0x8000000000000000ull >> p);
@@ -224,8 +228,9 @@ __device__ __forceinline__ void sparse_tile(uint64_t bm, uint32_t voff, uint32_t
         xv[j] = Buf<T>::ld(rx, has[j] ? xbase + (p & 7u) * (uint32_t)sizeof(T) : kOob);
     }
 #pragma unroll
-    for (int j = 0; j < kSparseMax; j++)
+    for (int j = 0; j < N; j++)
         if (has[j]) lds_add(trow + pr[j], a[j] * xv[j]);
+    return bm;
 }
 
 template <typename T>
@@ -238,22 +243,26 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
 {
     using A = typename Acc<T>::type;
     __shared__ A tile_all[4][kItemRows * 8];
-    __shared__ uint64_t q_bmp_all[4][kItemTiles];
-    __shared__ uint32_t q_off_all[4][kItemTiles], q_xb_all[4][kItemTiles], q_tb_all[4][kItemTiles];
+    // queues of tiles waiting for a full-wave pass: (bitmap, value byte offset, x byte offset, u-tile row base)
+    __shared__ uint64_t l_bmp_all[4][kLeftCap], d_bmp_all[4][kBatch];
+    __shared__ uint32_t l_off_all[4][kLeftCap], l_xb_all[4][kLeftCap], l_tb_all[4][kLeftCap];
+    __shared__ uint32_t d_off_all[4][kBatch], d_xb_all[4][kBatch], d_tb_all[4][kBatch];
     const int w = wave_id(), lane = lane_id();
     const uint32_t item_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
     if (item_id >= num_items) return;
     A *tile = tile_all[w];
-    uint64_t *q_bmp = q_bmp_all[w];
-    uint32_t *q_off = q_off_all[w], *q_xb = q_xb_all[w], *q_tb = q_tb_all[w];
+    uint64_t *l_bmp = l_bmp_all[w], *d_bmp = d_bmp_all[w];
+    uint32_t *l_off = l_off_all[w], *l_xb = l_xb_all[w], *l_tb = l_tb_all[w];
+    uint32_t *d_off = d_off_all[w], *d_xb = d_xb_all[w], *d_tb = d_tb_all[w];
     const SweepItem it = items[item_id];
     const rsrc_t rv = make_rsrc(values, values_bytes), rx = make_rsrc(x, num_cols * (uint32_t)sizeof(T));
     const uint64_t lt = lanemask_lt();
-#pragma unroll
-    for (int k = 0; k < 8; k++) tile[k * 64 + lane] = A(0);
+    tile[lane] = A(0);
+    tile[64 + lane] = A(0);
+    uint32_t n_left = 0;  // wave-uniform fill of the leftover queue
     __builtin_amdgcn_wave_barrier();
 
-    for (uint32_t base = it.blk_begin; base < it.blk_end; base += kItemTiles) {
+    for (uint32_t base = it.blk_begin; base < it.blk_end; base += kBatch) {
         // lane-per-tile: three coalesced streams, two tiles per lane
         const uint32_t b0 = base + lane, b1 = base + 64 + lane;
         uint64_t bm0 = 0, bm1 = 0, k0 = (uint64_t)it.row_begin << 32, k1 = k0, o0 = 0, o1 = 0;
@@ -262,49 +271,72 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
         const uint32_t x0 = key_col(k0) * 8u * (uint32_t)sizeof(T), x1 = key_col(k1) * 8u * (uint32_t)sizeof(T);
         const uint32_t tb0 = (key_row(k0) - it.row_begin) * 8u, tb1 = (key_row(k1) - it.row_begin) * 8u;
         const uint32_t vo0 = (uint32_t)o0 * (uint32_t)sizeof(T), vo1 = (uint32_t)o1 * (uint32_t)sizeof(T);
-        // tiles with many stored values are queued for the wave-wide pass
+        // dense tiles are queued for the wave-wide pass of this batch
         const bool d0 = __popcll(bm0) > kSparseMax, d1 = __popcll(bm1) > kSparseMax;
         const uint64_t m0 = __ballot(d0), m1 = __ballot(d1);
         const int n0 = __popcll(m0), qn = n0 + __popcll(m1);
         if (d0) {
             const int s = __popcll(m0 & lt);
-            q_bmp[s] = bm0; q_off[s] = vo0; q_xb[s] = x0; q_tb[s] = tb0;
+            d_bmp[s] = bm0; d_off[s] = vo0; d_xb[s] = x0; d_tb[s] = tb0;
         }
         if (d1) {
             const int s = n0 + __popcll(m1 & lt);
-            q_bmp[s] = bm1; q_off[s] = vo1; q_xb[s] = x1; q_tb[s] = tb1;
+            d_bmp[s] = bm1; d_off[s] = vo1; d_xb[s] = x1; d_tb[s] = tb1;
         }
-        // sparse tiles: one lane per tile, every load of both tiles in flight before the first LDS add
-        sparse_tile<T, A>(d0 ? 0ull : bm0, vo0, x0, tile + tb0, rv, rx);
-        sparse_tile<T, A>(d1 ? 0ull : bm1, vo1, x1, tile + tb1, rv, rx);
+        // every sparse tile: its first kInlineSlots stored values right here (covers most tiles of a graph matrix entirely)
+        const uint64_t r0 = peel_tile<T, A, kInlineSlots>(d0 ? 0ull : bm0, vo0, x0, tile + tb0, rv, rx);
+        const uint64_t r1 = peel_tile<T, A, kInlineSlots>(d1 ? 0ull : bm1, vo1, x1, tile + tb1, rv, rx);
+        // tiles with more values wait in the leftover queue until 64 of them make a full wave
+        const uint64_t lm0 = __ballot(r0 != 0), lm1 = __ballot(r1 != 0);
+        if (r0) {
+            const uint32_t s = n_left + (uint32_t)__popcll(lm0 & lt);
+            l_bmp[s] = r0; l_off[s] = vo0 + kInlineSlots * (uint32_t)sizeof(T); l_xb[s] = x0; l_tb[s] = tb0;
+        }
+        n_left += (uint32_t)__popcll(lm0);
+        if (r1) {
+            const uint32_t s = n_left + (uint32_t)__popcll(lm1 & lt);
+            l_bmp[s] = r1; l_off[s] = vo1 + kInlineSlots * (uint32_t)sizeof(T); l_xb[s] = x1; l_tb[s] = tb1;
+        }
+        n_left += (uint32_t)__popcll(lm1);
         __builtin_amdgcn_wave_barrier();
+        while (n_left >= 64u) {
+            n_left -= 64u;
+            const uint32_t s = n_left + (uint32_t)lane;
+            peel_tile<T, A, kSparseMax - kInlineSlots>(l_bmp[s], l_off[s], l_xb[s], tile + l_tb[s], rv, rx);
+        }
         // dense tiles: the whole wave per tile, lane p owns tile position p (coalesced value loads), kDenseTrip tiles per trip
         for (int q = 0; q < qn; q += kDenseTrip) {
             A pa[kDenseTrip];
 #pragma unroll
             for (int t = 0; t < kDenseTrip; t++) {
                 const int e = min(q + t, qn - 1);
-                const uint64_t bb = q + t < qn ? q_bmp[e] : 0ull;
+                const uint64_t bb = q + t < qn ? d_bmp[e] : 0ull;
                 const bool has = tile_has(bb, lane);
-                const A av = Buf<T>::ld(rv, has ? q_off[e] + (uint32_t)tile_rank(bb, lane) * (uint32_t)sizeof(T) : kOob);
-                const A xx = Buf<T>::ld(rx, has ? q_xb[e] + ((uint32_t)lane & 7u) * (uint32_t)sizeof(T) : kOob);
+                const A av = Buf<T>::ld(rv, has ? d_off[e] + (uint32_t)tile_rank(bb, lane) * (uint32_t)sizeof(T) : kOob);
+                const A xx = Buf<T>::ld(rx, has ? d_xb[e] + ((uint32_t)lane & 7u) * (uint32_t)sizeof(T) : kOob);
                 pa[t] = av * xx;
             }
 #pragma unroll
             for (int t = 0; t < kDenseTrip; t++) {
                 const int e = min(q + t, qn - 1);
                 const A sum = row8_sum(pa[t]);
-                if (q + t < qn && (lane & 7) == 0 && tile_byte(q_bmp[e], lane >> 3)) lds_add(tile + q_tb[e] + (lane >> 3), sum);
+                if (q + t < qn && (lane & 7) == 0 && tile_byte(d_bmp[e], lane >> 3)) lds_add(tile + d_tb[e] + (lane >> 3), sum);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
+    // the leftover tiles that never filled a wave
+    if (n_left) {
+        const bool on = (uint32_t)lane < n_left;
+        peel_tile<T, A, kSparseMax - kInlineSlots>(on ? l_bmp[lane] : 0ull, on ? l_off[lane] : 0u, on ? l_xb[lane] : 0u, tile + (on ? l_tb[lane] : 0u), rv, rx);
+    }
+    __builtin_amdgcn_wave_barrier();
 
     if (it.num_items == 0) {
         // short item: the wave owns u[row_begin*8, row_end*8)
         const uint32_t n_out = (it.row_end - it.row_begin) * 8u, out0 = it.row_begin * 8u;
-        for (uint32_t e = lane; e < n_out; e += 64)
-            if (out0 + e < num_rows) y[out0 + e] = tile[e];
+        if ((uint32_t)lane < n_out && out0 + lane < num_rows) y[out0 + lane] = tile[lane];
+        if (64u + (uint32_t)lane < n_out && out0 + 64u + lane < num_rows) y[out0 + 64u + lane] = tile[64 + lane];
         return;
     }
     // long row: park the partial sums, the last arriver folds them.  Write-through (sc1) stores + drained vmcnt +
