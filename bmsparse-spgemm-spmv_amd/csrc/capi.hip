@@ -4,6 +4,7 @@
 #include "prims.hip.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -247,6 +248,68 @@ int bmsp_matrix_from_arrays(int num_rows, int num_cols, int64_t block_num, int64
         m->ownership = 2;
         m->keys = d_keys; m->bmps = d_bmps; m->offsets = d_offsets; m->values = d_values;
     }
+    *out = m.release();
+    BMSP_API_END
+}
+
+namespace {
+struct CacheHeader {
+    char magic[8];
+    int32_t num_rows, num_cols, dtype, transposed;
+    int64_t block_num, nnz;
+};
+const char kCacheMagic[8] = {'B', 'M', 'S', 'P', 'v', '1', 0, 0};
+}  // namespace
+
+int bmsp_matrix_save(bmsp_matrix_t m, const char *path)
+{
+    BMSP_API_BEGIN
+    need(m, "matrix"); need(path, "path");
+    if (m->ownership == 2 && m->view_block_begin) fail(BMSP_ERR_UNSUPPORTED, "row-panel views cannot be saved; save the parent");
+    FILE *f = fopen(path, "wb");
+    if (!f) fail(BMSP_ERR_IO, "cannot create '%s'", path);
+    std::unique_ptr<FILE, int (*)(FILE *)> guard(f, fclose);
+    CacheHeader h;
+    memcpy(h.magic, kCacheMagic, 8);
+    h.num_rows = m->num_rows; h.num_cols = m->num_cols; h.dtype = (int32_t)m->dtype; h.transposed = m->transposed;
+    h.block_num = m->block_num; h.nnz = m->nnz;
+    const size_t nb = (size_t)m->block_num, es = dtype_size(m->dtype);
+    std::vector<char> buf;
+    auto dump = [&](const void *dptr, size_t bytes) {
+        buf.resize(bytes);
+        if (bytes) BMSP_HIP(hipMemcpy(buf.data(), dptr, bytes, hipMemcpyDeviceToHost));
+        if (bytes && fwrite(buf.data(), 1, bytes, f) != bytes) fail(BMSP_ERR_IO, "short write to '%s'", path);
+    };
+    if (fwrite(&h, sizeof h, 1, f) != 1) fail(BMSP_ERR_IO, "short write to '%s'", path);
+    dump(m->keys, 8 * nb); dump(m->bmps, 8 * nb); dump(m->offsets, 8 * (nb + 1)); dump(m->values, es * (size_t)m->nnz);
+    BMSP_API_END
+}
+
+int bmsp_matrix_load(const char *path, bmsp_matrix_t *out)
+{
+    BMSP_API_BEGIN
+    need(path, "path"); need(out, "out");
+    FILE *f = fopen(path, "rb");
+    if (!f) fail(BMSP_ERR_IO, "cannot open '%s'", path);
+    std::unique_ptr<FILE, int (*)(FILE *)> guard(f, fclose);
+    CacheHeader h;
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, kCacheMagic, 8) != 0) fail(BMSP_ERR_IO, "'%s' is not a bmSparse cache file", path);
+    if (h.block_num < 0 || h.nnz < 0 || h.num_rows < 0 || h.num_cols < 0 || h.dtype < 0 || h.dtype > 2) fail(BMSP_ERR_IO, "'%s': corrupt header", path);
+    std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> m(new bmsp_matrix_s(), free_matrix);
+    m->num_rows = h.num_rows; m->num_cols = h.num_cols; m->dtype = (bmsp_dtype)h.dtype; m->transposed = h.transposed ? 1 : 0;
+    m->block_num = h.block_num; m->nnz = h.nnz;
+    const size_t nb = (size_t)h.block_num, es = dtype_size(m->dtype);
+    std::vector<char> buf;
+    auto slurp = [&](void **dptr, size_t bytes) {
+        *dptr = pool_alloc(bytes ? bytes : 8);
+        buf.resize(bytes);
+        if (bytes && fread(buf.data(), 1, bytes, f) != bytes) fail(BMSP_ERR_IO, "'%s' is truncated", path);
+        if (bytes) BMSP_HIP(hipMemcpy(*dptr, buf.data(), bytes, hipMemcpyHostToDevice));
+    };
+    slurp((void **)&m->keys, 8 * nb); slurp((void **)&m->bmps, 8 * nb); slurp((void **)&m->offsets, 8 * (nb + 1));
+    slurp(&m->values, es * (size_t)h.nnz);
+    ensure_rowptr(m.get(), nullptr);
+    BMSP_HIP(hipStreamSynchronize(nullptr));
     *out = m.release();
     BMSP_API_END
 }

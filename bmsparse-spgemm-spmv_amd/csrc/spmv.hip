@@ -185,8 +185,10 @@ struct Buf<double> {
 
 constexpr int kSparseMax = 8;   // tiles with more stored values than this go to the wave-wide dense pass
 constexpr int kInlineSlots = 2; // stored values of a tile handled in the streaming loop; the rest of a tile waits in a queue
+                                // (1, 2 and 3 measure the same within 2 %)
 constexpr int kDenseTrip = 8;   // dense tiles per trip of the wave-wide pass
-constexpr uint32_t kLeftCap = 64 + kBatch;  // leftover queue: flushed 64 tiles at a time, so every lane has work
+constexpr uint32_t kLeftCap = 128;  // leftover queue: flushed 64 tiles at a time, so every lane has work
+constexpr uint32_t kDenseCap = 64;  // dense queue, swept after each half batch
 
 template <typename A>
 __device__ __forceinline__ void lds_add(A *p, A v)
@@ -244,9 +246,9 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
     using A = typename Acc<T>::type;
     __shared__ A tile_all[4][kItemRows * 8];
     // queues of tiles waiting for a full-wave pass: (bitmap, value byte offset, x byte offset, u-tile row base)
-    __shared__ uint64_t l_bmp_all[4][kLeftCap], d_bmp_all[4][kBatch];
+    __shared__ uint64_t l_bmp_all[4][kLeftCap], d_bmp_all[4][kDenseCap];
     __shared__ uint32_t l_off_all[4][kLeftCap], l_xb_all[4][kLeftCap], l_tb_all[4][kLeftCap];
-    __shared__ uint32_t d_off_all[4][kBatch], d_xb_all[4][kBatch], d_tb_all[4][kBatch];
+    __shared__ uint32_t d_off_all[4][kDenseCap], d_xb_all[4][kDenseCap], d_tb_all[4][kDenseCap];
     const int w = wave_id(), lane = lane_id();
     const uint32_t item_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
     if (item_id >= num_items) return;
@@ -271,59 +273,55 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
         const uint32_t x0 = key_col(k0) * 8u * (uint32_t)sizeof(T), x1 = key_col(k1) * 8u * (uint32_t)sizeof(T);
         const uint32_t tb0 = (key_row(k0) - it.row_begin) * 8u, tb1 = (key_row(k1) - it.row_begin) * 8u;
         const uint32_t vo0 = (uint32_t)o0 * (uint32_t)sizeof(T), vo1 = (uint32_t)o1 * (uint32_t)sizeof(T);
-        // dense tiles are queued for the wave-wide pass of this batch
-        const bool d0 = __popcll(bm0) > kSparseMax, d1 = __popcll(bm1) > kSparseMax;
-        const uint64_t m0 = __ballot(d0), m1 = __ballot(d1);
-        const int n0 = __popcll(m0), qn = n0 + __popcll(m1);
-        if (d0) {
-            const int s = __popcll(m0 & lt);
-            d_bmp[s] = bm0; d_off[s] = vo0; d_xb[s] = x0; d_tb[s] = tb0;
-        }
-        if (d1) {
-            const int s = n0 + __popcll(m1 & lt);
-            d_bmp[s] = bm1; d_off[s] = vo1; d_xb[s] = x1; d_tb[s] = tb1;
-        }
-        // every sparse tile: its first kInlineSlots stored values right here (covers most tiles of a graph matrix entirely)
-        const uint64_t r0 = peel_tile<T, A, kInlineSlots>(d0 ? 0ull : bm0, vo0, x0, tile + tb0, rv, rx);
-        const uint64_t r1 = peel_tile<T, A, kInlineSlots>(d1 ? 0ull : bm1, vo1, x1, tile + tb1, rv, rx);
-        // tiles with more values wait in the leftover queue until 64 of them make a full wave
-        const uint64_t lm0 = __ballot(r0 != 0), lm1 = __ballot(r1 != 0);
-        if (r0) {
-            const uint32_t s = n_left + (uint32_t)__popcll(lm0 & lt);
-            l_bmp[s] = r0; l_off[s] = vo0 + kInlineSlots * (uint32_t)sizeof(T); l_xb[s] = x0; l_tb[s] = tb0;
-        }
-        n_left += (uint32_t)__popcll(lm0);
-        if (r1) {
-            const uint32_t s = n_left + (uint32_t)__popcll(lm1 & lt);
-            l_bmp[s] = r1; l_off[s] = vo1 + kInlineSlots * (uint32_t)sizeof(T); l_xb[s] = x1; l_tb[s] = tb1;
-        }
-        n_left += (uint32_t)__popcll(lm1);
-        __builtin_amdgcn_wave_barrier();
-        while (n_left >= 64u) {
-            n_left -= 64u;
-            const uint32_t s = n_left + (uint32_t)lane;
-            peel_tile<T, A, kSparseMax - kInlineSlots>(l_bmp[s], l_off[s], l_xb[s], tile + l_tb[s], rv, rx);
-        }
-        // dense tiles: the whole wave per tile, lane p owns tile position p (coalesced value loads), kDenseTrip tiles per trip
-        for (int q = 0; q < qn; q += kDenseTrip) {
-            A pa[kDenseTrip];
+        // the two tiles of a lane are handled one after the other so that the queues never hold more than 64 new entries
 #pragma unroll
-            for (int t = 0; t < kDenseTrip; t++) {
-                const int e = min(q + t, qn - 1);
-                const uint64_t bb = q + t < qn ? d_bmp[e] : 0ull;
-                const bool has = tile_has(bb, lane);
-                const A av = Buf<T>::ld(rv, has ? d_off[e] + (uint32_t)tile_rank(bb, lane) * (uint32_t)sizeof(T) : kOob);
-                const A xx = Buf<T>::ld(rx, has ? d_xb[e] + ((uint32_t)lane & 7u) * (uint32_t)sizeof(T) : kOob);
-                pa[t] = av * xx;
+        for (int h = 0; h < 2; h++) {
+            const uint64_t bm = h ? bm1 : bm0;
+            const uint32_t vo = h ? vo1 : vo0, xb = h ? x1 : x0, tb = h ? tb1 : tb0;
+            // dense tiles are queued for the wave-wide pass
+            const bool dense = __popcll(bm) > kSparseMax;
+            const uint64_t dm = __ballot(dense);
+            const int qn = __popcll(dm);
+            if (dense) {
+                const int s = __popcll(dm & lt);
+                d_bmp[s] = bm; d_off[s] = vo; d_xb[s] = xb; d_tb[s] = tb;
             }
+            // every sparse tile: its first kInlineSlots stored values right here (covers most tiles of a graph matrix entirely)
+            const uint64_t rest = peel_tile<T, A, kInlineSlots>(dense ? 0ull : bm, vo, xb, tile + tb, rv, rx);
+            // tiles with more values wait in the leftover queue until 64 of them make a full wave
+            const uint64_t lm = __ballot(rest != 0);
+            if (rest) {
+                const uint32_t s = n_left + (uint32_t)__popcll(lm & lt);
+                l_bmp[s] = rest; l_off[s] = vo + kInlineSlots * (uint32_t)sizeof(T); l_xb[s] = xb; l_tb[s] = tb;
+            }
+            n_left += (uint32_t)__popcll(lm);
+            __builtin_amdgcn_wave_barrier();
+            if (n_left >= 64u) {
+                n_left -= 64u;
+                const uint32_t s = n_left + (uint32_t)lane;
+                peel_tile<T, A, kSparseMax - kInlineSlots>(l_bmp[s], l_off[s], l_xb[s], tile + l_tb[s], rv, rx);
+            }
+            // dense tiles: the whole wave per tile, lane p owns tile position p (coalesced value loads), kDenseTrip tiles per trip
+            for (int q = 0; q < qn; q += kDenseTrip) {
+                A pa[kDenseTrip];
 #pragma unroll
-            for (int t = 0; t < kDenseTrip; t++) {
-                const int e = min(q + t, qn - 1);
-                const A sum = row8_sum(pa[t]);
-                if (q + t < qn && (lane & 7) == 0 && tile_byte(d_bmp[e], lane >> 3)) lds_add(tile + d_tb[e] + (lane >> 3), sum);
+                for (int t = 0; t < kDenseTrip; t++) {
+                    const int e = min(q + t, qn - 1);
+                    const uint64_t bb = q + t < qn ? d_bmp[e] : 0ull;
+                    const bool has = tile_has(bb, lane);
+                    const A av = Buf<T>::ld(rv, has ? d_off[e] + (uint32_t)tile_rank(bb, lane) * (uint32_t)sizeof(T) : kOob);
+                    const A xx = Buf<T>::ld(rx, has ? d_xb[e] + ((uint32_t)lane & 7u) * (uint32_t)sizeof(T) : kOob);
+                    pa[t] = av * xx;
+                }
+#pragma unroll
+                for (int t = 0; t < kDenseTrip; t++) {
+                    const int e = min(q + t, qn - 1);
+                    const A sum = row8_sum(pa[t]);
+                    if (q + t < qn && (lane & 7) == 0 && tile_byte(d_bmp[e], lane >> 3)) lds_add(tile + d_tb[e] + (lane >> 3), sum);
+                }
             }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
     // the leftover tiles that never filled a wave
     if (n_left) {
@@ -335,8 +333,8 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
     if (it.num_items == 0) {
         // short item: the wave owns u[row_begin*8, row_end*8)
         const uint32_t n_out = (it.row_end - it.row_begin) * 8u, out0 = it.row_begin * 8u;
-        if ((uint32_t)lane < n_out && out0 + lane < num_rows) y[out0 + lane] = tile[lane];
-        if (64u + (uint32_t)lane < n_out && out0 + 64u + lane < num_rows) y[out0 + 64u + lane] = tile[64 + lane];
+        for (uint32_t e = lane; e < n_out; e += 64)
+            if (out0 + e < num_rows) y[out0 + e] = tile[e];
         return;
     }
     // long row: park the partial sums, the last arriver folds them.  Write-through (sc1) stores + drained vmcnt +

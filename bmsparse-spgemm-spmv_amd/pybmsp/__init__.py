@@ -26,7 +26,7 @@ SYMBOLS = [
     "bmsp_memcpy_h2d", "bmsp_memcpy_d2h", "bmsp_memcpy_d2d", "bmsp_memset", "bmsp_synchronize", "bmsp_trim_pool",
     "bmsp_event_create", "bmsp_event_record", "bmsp_event_elapsed_ms", "bmsp_event_destroy",
     "bmsp_matrix_from_mtx", "bmsp_matrix_from_coo", "bmsp_matrix_from_coo_device", "bmsp_matrix_from_arrays",
-    "bmsp_matrix_free", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
+    "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
     "bmsp_matrix_to_coo_host", "bmsp_matrix_compare", "bmsp_spmv", "bmsp_spgemm", "bmsp_segsort_u64",
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
@@ -84,6 +84,8 @@ def lib():
         L.bmsp_matrix_from_coo.argtypes = [i, i, i64, vp, vp, vp, i, i, p(vp)]
         L.bmsp_matrix_from_coo_device.argtypes = [i, i, i64, vp, vp, vp, i, i, vp, p(vp)]
         L.bmsp_matrix_from_arrays.argtypes = [i, i, i64, i64, vp, vp, vp, vp, i, i, i, p(vp)]
+        L.bmsp_matrix_save.argtypes = [vp, C.c_char_p]
+        L.bmsp_matrix_load.argtypes = [C.c_char_p, p(vp)]
         L.bmsp_matrix_free.argtypes = [vp]
         L.bmsp_matrix_info.argtypes = [vp, p(i), p(i), p(i64), p(i64), p(i), p(i)]
         L.bmsp_matrix_arrays.argtypes = [vp, p(vp), p(vp), p(vp), p(vp)]
@@ -235,6 +237,15 @@ class BmSpMatrix:
                                             int(bool(transposed)), 1, C.byref(h)))
         for d in (k, b, o, v):
             d.release()
+        return BmSpMatrix(h.value)
+
+    def save(self, path):
+        check(lib().bmsp_matrix_save(self.h, os.fsencode(path)))
+
+    @staticmethod
+    def load(path):
+        h = C.c_void_p()
+        check(lib().bmsp_matrix_load(os.fsencode(path), C.byref(h)))
         return BmSpMatrix(h.value)
 
     def info(self):

@@ -94,6 +94,12 @@ int bmsp_matrix_from_arrays(int num_rows, int num_cols, int64_t block_num, int64
                             uint64_t *d_bmps, uint64_t *d_offsets, void *d_values, bmsp_dtype dtype,
                             int transposed, int ownership, bmsp_matrix_t *out);
 
+/* Binary cache of the built matrix (the reference only hints at "Dumping bmSparse matrices to disk",
+ * src/bmSparse_SPGEMM.cu:21,27): header + keys + bmps + offsets + values, so a SuiteSparse file is parsed and
+ * sorted once.  bmsp_matrix_load restores exactly what bmsp_matrix_save wrote (bit-identical arrays). */
+int bmsp_matrix_save(bmsp_matrix_t m, const char *path);
+int bmsp_matrix_load(const char *path, bmsp_matrix_t *out);
+
 int bmsp_matrix_free(bmsp_matrix_t m);
 
 /* public members of bmSpMatrix<T>: num_rows, num_cols, nnz, block_num (include/bmSpMatrix.h:32) */

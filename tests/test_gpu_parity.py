@@ -484,3 +484,23 @@ def test_cli_executables_and_batch_scripts(tmp_path):
         assert r.returncode == 0, r.stderr
         assert r.stdout.count("Working on") == 2
         assert (tmp_path / outfile).read_text().count(needle) == 2
+
+
+def test_binary_cache_roundtrip(oracle, bmsp, tmp_path):
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(10, 5)
+    for dtype in (0, 1, 2):
+        for transposed in (False, True):
+            m = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=transposed, dtype=dtype)
+            path = str(tmp_path / ("m_%d_%d.bmsp" % (dtype, transposed)))
+            m.save(path)
+            m2 = bmsp.BmSpMatrix.load(path)
+            assert m.info() == m2.info()
+            for x, y in zip(m.host_arrays(), m2.host_arrays()):
+                np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
+            np.testing.assert_array_equal(m.block_row_ptr(), m2.block_row_ptr())
+    with pytest.raises(bmsp.BmspError):
+        bmsp.BmSpMatrix.load(os.path.join(MTX, "real", "A_matrix.mtx"))  # not a cache file
+    open(str(tmp_path / "trunc.bmsp"), "wb").write(open(path, "rb").read()[:100])
+    with pytest.raises(bmsp.BmspError):
+        bmsp.BmSpMatrix.load(str(tmp_path / "trunc.bmsp"))
