@@ -162,7 +162,7 @@ def main():
     traffic = None
     if "coo" in wl and not args.spmv_matrix and args.scale == 20 and args.edge_factor == 2.0:
         import glob
-        for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_spmv_webbase_like_traffic.json"))):
+        for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_spmv_webbase_like*_traffic.json"))):
             traffic = json.load(open(f))["traffic_bytes_per_launch"]
     roofline = {"bound": "hbm", "kernel": "spmv_sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
