@@ -61,7 +61,8 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int
 template <typename T>
 struct PingPong;
 // stable sort of (key, task) pairs inside the runs of equal (key >> jbits): the SpGEMM's segmented path
-void segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, int ibits, hipStream_t st);
+// false = some block-row has more tasks than the LDS paths hold; nothing was modified and the caller sorts globally
+bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st);
 void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const int *d_segs, int64_t num_segs,
                  hipStream_t st);
 

@@ -4,8 +4,14 @@
 // by bmSparse_mult with K = uint64_t C keys, T = 16-byte tasks and one segment per block-row of A
 // (src/bmSparse_SPGEMM.cu:973-1010).  bb_segsort is unstable; this one is stable.
 //
-// Version 1 (correctness baseline, also the fallback for very long segments): two stable LSD radix sorts of a
-// permutation -- first by the key bits that actually vary, then by segment number -- followed by one gather.
+// Segments are binned by length like bb_segsort does (bb_segsort.h:63-171), with wave64 shapes:
+//   length <= 1            nothing to do
+//   2 .. 256               one WAVE per segment: the segment lives in LDS (4 elements per lane) and is sorted by a
+//                          bitonic network on the composite (key, position) -- the position makes the order stable
+//   257 .. 4096            one 512-thread workgroup per segment, same network with workgroup barriers
+//   longer                 (hub segments) fallback: two stable LSD radix sorts of a permutation -- by the key bits that
+//                          vary, then by segment number -- over the whole array
+// Every path produces a permutation; values move once, through one gather (as bb_segsort does, bb_comput_s.h:88).
 #include "matrix.h"
 #include "prims.hip.h"
 
@@ -45,6 +51,11 @@ struct VaryingBits {
 struct VaryingBitsClamped {
     VaryingBits f;
     __device__ void operator()(uint64_t i) const { f(i < f.n ? i : f.n - 1); }
+};
+
+struct Iota32Seg {
+    uint32_t *p;
+    __device__ void operator()(uint64_t i) const { p[i] = (uint32_t)i; }
 };
 
 struct CopyKeysIota {
@@ -114,6 +125,169 @@ void segsort_impl(uint64_t *keys, V *vals, uint64_t n, const int *segs, uint32_t
     BMSP_HIP(hipStreamSynchronize(st));
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS bitonic paths
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kWaveSegMax = 256, kBlockSegMax = 4096;
+
+struct SegClassify {
+    const int *segs;
+    uint32_t nseg;
+    uint64_t n;
+    __device__ uint32_t len(uint64_t s) const
+    {
+        const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
+        return hi > lo ? (uint32_t)(hi - lo) : 0u;
+    }
+    // packed counts: [0,21) wave-class segments, [21,42) block-class, [42,63) long
+    __device__ uint64_t operator()(uint64_t s) const
+    {
+        if (s >= nseg) return 0;
+        const uint32_t l = len(s);
+        if (l <= 1) return 0;
+        return l <= kWaveSegMax ? 1ull : (l <= kBlockSegMax ? 1ull << 21 : 1ull << 42);
+    }
+};
+struct SegLists {
+    SegClassify c;
+    uint32_t *wave_list, *block_list;
+    uint64_t *totals;
+    uint32_t *perm;  // identity is written for unit segments
+    __device__ void operator()(uint64_t s, uint64_t ex) const
+    {
+        if (s == c.nseg) { *totals = ex; return; }
+        const uint32_t l = c.len(s);
+        if (l == 1) perm[c.segs[s]] = (uint32_t)c.segs[s];
+        if (l <= 1) return;
+        if (l <= kWaveSegMax) wave_list[ex & 0x1fffffu] = (uint32_t)s;
+        else if (l <= kBlockSegMax) block_list[(ex >> 21) & 0x1fffffu] = (uint32_t)s;
+    }
+};
+
+__device__ __forceinline__ bool composite_greater(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib)
+{
+    return ka > kb || (ka == kb && ia > ib);
+}
+
+// sorts P (power of two) composite elements held in LDS; every participating thread calls this with the same P.
+template <int THREADS, bool BLOCK_SYNC>
+__device__ __forceinline__ void bitonic_lds(uint64_t *key, uint16_t *idx, uint32_t P, uint32_t tid)
+{
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t p = tid; p < P / 2; p += THREADS) {
+                const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const uint32_t q = i | j;
+                const uint64_t ka = key[i], kb = key[q];
+                const uint32_t ia = idx[i], ib = idx[q];
+                const bool up = (i & k) == 0;
+                if (composite_greater(ka, ia, kb, ib) == up) {
+                    key[i] = kb; key[q] = ka;
+                    idx[i] = (uint16_t)ib; idx[q] = (uint16_t)ia;
+                }
+            }
+            if (BLOCK_SYNC) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void segsort_wave_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, const int *__restrict__ segs,
+                                                                uint32_t nseg, uint64_t n, const uint32_t *__restrict__ list, uint32_t count)
+{
+    __shared__ uint64_t s_key[4][kWaveSegMax];
+    __shared__ uint16_t s_idx[4][kWaveSegMax];
+    const int w = wave_id(), lane = lane_id();
+    const uint32_t li = blockIdx.x * 4 + w;
+    if (li >= count) return;
+    const uint32_t s = list[li];
+    const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
+    const uint32_t len = (uint32_t)(hi - lo);
+    uint32_t P = 2;
+    while (P < len) P <<= 1;
+    uint64_t *key = s_key[w];
+    uint16_t *idx = s_idx[w];
+    for (uint32_t e = lane; e < P; e += 64) {
+        key[e] = e < len ? keys[lo + e] : ~0ull;
+        idx[e] = e < len ? (uint16_t)e : (uint16_t)0xffff;
+    }
+    __builtin_amdgcn_wave_barrier();
+    bitonic_lds<64, false>(key, idx, P, (uint32_t)lane);
+    for (uint32_t e = lane; e < len; e += 64) {
+        keys[lo + e] = key[e];
+        perm[lo + e] = (uint32_t)(lo + idx[e]);
+    }
+}
+
+__global__ __launch_bounds__(512) void segsort_block_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, const int *__restrict__ segs,
+                                                            uint32_t nseg, uint64_t n, const uint32_t *__restrict__ list)
+{
+    __shared__ uint64_t key[kBlockSegMax];
+    __shared__ uint16_t idx[kBlockSegMax];
+    const uint32_t s = list[blockIdx.x];
+    const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
+    const uint32_t len = (uint32_t)(hi - lo);
+    uint32_t P = 512;
+    while (P < len) P <<= 1;
+    for (uint32_t e = threadIdx.x; e < P; e += 512) {
+        key[e] = e < len ? keys[lo + e] : ~0ull;
+        idx[e] = e < len ? (uint16_t)e : (uint16_t)0xffff;
+    }
+    __syncthreads();
+    bitonic_lds<512, true>(key, idx, P, threadIdx.x);
+    for (uint32_t e = threadIdx.x; e < len; e += 512) {
+        keys[lo + e] = key[e];
+        perm[lo + e] = (uint32_t)(lo + idx[e]);
+    }
+}
+
+template <typename V>
+struct GatherVals {
+    const V *vin;
+    const uint32_t *perm;
+    V *vout;
+    __device__ void operator()(uint64_t i) const { vout[i] = vin[perm[i]]; }
+};
+
+// Sorts every segment in place through LDS and writes the permutation that was applied (perm[i] = source position of
+// the element now at i).  Returns false -- with nothing modified -- when some segment is too long for the LDS paths.
+// `segs[0]` must be 0 unless `perm` was pre-filled with the identity.
+bool segsort_lds_perm(uint64_t *keys, uint32_t *perm, uint64_t n, const int *segs, uint32_t nseg, hipStream_t st)
+{
+    if (nseg >= (1u << 21)) return false;  // packed 21-bit class counters
+    SegClassify cls{segs, nseg, n};
+    DevBuf<uint32_t> wave_list(nseg), block_list(nseg);
+    DevBuf<uint64_t> tot(1);
+    device_exclusive_scan<uint64_t>(cls, SegLists{cls, wave_list.p, block_list.p, tot.p, perm}, (uint64_t)nseg + 1, st);
+    const uint64_t t = read_back(tot.p, st);
+    const uint32_t n_wave = (uint32_t)(t & 0x1fffffu), n_block = (uint32_t)((t >> 21) & 0x1fffffu), n_long = (uint32_t)(t >> 42);
+    if (n_long) return false;
+    if (n_wave) {
+        hipLaunchKernelGGL(segsort_wave_kernel, dim3((n_wave + 3) / 4), dim3(kThreads), 0, st, keys, perm, segs, nseg, n, wave_list.p, n_wave);
+        BMSP_CHECK_LAUNCH();
+    }
+    if (n_block) {
+        hipLaunchKernelGGL(segsort_block_kernel, dim3(n_block), dim3(512), 0, st, keys, perm, segs, nseg, n, block_list.p);
+        BMSP_CHECK_LAUNCH();
+    }
+    return true;
+}
+
+template <typename V>
+bool segsort_lds(uint64_t *keys, V *vals, uint64_t n, const int *segs, uint32_t nseg, hipStream_t st)
+{
+    DevBuf<uint32_t> perm(n);
+    device_for_each(Iota32Seg{perm.p}, n, st);  // positions outside every segment stay put
+    if (!segsort_lds_perm(keys, perm.p, n, segs, nseg, st)) return false;
+    if (vals) {
+        DevBuf<V> vtmp(n);
+        device_for_each(GatherVals<V>{vals, perm.p, vtmp.p}, n, st);
+        BMSP_HIP(hipMemcpyAsync(vals, vtmp.p, sizeof(V) * n, hipMemcpyDeviceToDevice, st));
+    }
+    BMSP_HIP(hipStreamSynchronize(st));
+    return true;
+}
+
 struct RunHead {
     const uint64_t *keys;
     uint64_t n;
@@ -157,29 +331,29 @@ void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const
     if (n == 0 || num_segs == 0) return;
     if (n >= (1ll << 31)) fail(BMSP_ERR_LIMIT, "segmented sort handles < 2^31 elements (int segment starts)");
     if (!d_keys || !d_segs) fail(BMSP_ERR_INVALID, "null pointer");
-    if (!d_vals) segsort_impl<uint32_t>(d_keys, nullptr, (uint64_t)n, d_segs, (uint32_t)num_segs, st);
-    else if (val_bytes == 4) segsort_impl<uint32_t>(d_keys, (uint32_t *)d_vals, (uint64_t)n, d_segs, (uint32_t)num_segs, st);
-    else if (val_bytes == 8) segsort_impl<uint64_t>(d_keys, (uint64_t *)d_vals, (uint64_t)n, d_segs, (uint32_t)num_segs, st);
-    else if (val_bytes == 16) segsort_impl<Pair16>(d_keys, (Pair16 *)d_vals, (uint64_t)n, d_segs, (uint32_t)num_segs, st);
+    const uint64_t un = (uint64_t)n;
+    const uint32_t ns = (uint32_t)num_segs;
+    if (!d_vals) { if (!segsort_lds<uint32_t>(d_keys, nullptr, un, d_segs, ns, st)) segsort_impl<uint32_t>(d_keys, nullptr, un, d_segs, ns, st); }
+    else if (val_bytes == 4) { if (!segsort_lds<uint32_t>(d_keys, (uint32_t *)d_vals, un, d_segs, ns, st)) segsort_impl<uint32_t>(d_keys, (uint32_t *)d_vals, un, d_segs, ns, st); }
+    else if (val_bytes == 8) { if (!segsort_lds<uint64_t>(d_keys, (uint64_t *)d_vals, un, d_segs, ns, st)) segsort_impl<uint64_t>(d_keys, (uint64_t *)d_vals, un, d_segs, ns, st); }
+    else if (val_bytes == 16) { if (!segsort_lds<Pair16>(d_keys, (Pair16 *)d_vals, un, d_segs, ns, st)) segsort_impl<Pair16>(d_keys, (Pair16 *)d_vals, un, d_segs, ns, st); }
     else fail(BMSP_ERR_INVALID, "val_bytes must be 4, 8 or 16");
 }
 
-void segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, int ibits, hipStream_t st)
+bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st)
 {
-    (void)ibits;
-    if (n >= (1ull << 31)) fail(BMSP_ERR_LIMIT, "segmented sort handles < 2^31 tasks");
-    // segments = runs of equal block-row (reference: :982-1004)
+    if (n >= (1ull << 31)) return false;
+    // segments = runs of equal block-row (reference: :982-1004).  Inside a run the row part of the packed key is
+    // constant, so comparing whole keys orders by column: no masking pass is needed.
     DevBuf<int> segs(n);
     DevBuf<uint32_t> cnt(1);
     device_exclusive_scan<uint32_t>(RunHead{keys.cur, n, jbits}, EmitRunStarts{keys.cur, n, jbits, segs.p, cnt.p}, n + 1, st);
-    uint32_t nseg = read_back(cnt.p, st);
-    // sort the column part inside each segment, then put the row part back
-    const uint64_t mask = (1ull << jbits) - 1ull;
-    device_for_each(MaskLow{keys.alt, keys.cur, mask}, n, st);
-    segsort_u64(keys.alt, vals.cur, 8, (int64_t)n, segs.p, nseg, st);
-    device_for_each(RestoreHigh{keys.alt, keys.cur, mask}, n, st);
-    keys.flip();
-    BMSP_HIP(hipStreamSynchronize(st));
+    const uint32_t nseg = read_back(cnt.p, st);
+    DevBuf<uint32_t> perm(n);
+    if (!segsort_lds_perm(keys.cur, perm.p, n, segs.p, nseg, st)) return false;  // hub rows: caller takes the global sort
+    device_for_each(GatherVals<uint64_t>{vals.cur, perm.p, vals.alt}, n, st);
+    vals.flip();
+    return true;
 }
 
 }  // namespace bmsp

@@ -376,6 +376,158 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_kernel(const uint
     }
 }
 
+// ---- T_7, task-parallel operand fetch, software-pipelined over C-block groups ------------------------------------
+// The kernel above walks each C block's task list with the whole wave, so a wave has one dependent chain
+// (task_begin -> task -> bitmaps/offsets -> values) per C-block pair in flight and the stage is bound by memory round trips
+// (profiles/r01c_spgemm_cage_like_summary.md: 59 % of wave cycles parked on s_waitcnt at 4.5 waves/SIMD).  Here a wave
+// owns 16 consecutive C blocks (8 MFMA pairs) per step and turns the chain sideways:
+//   * the tasks of those blocks are one contiguous range of the sorted task list, so 64 LANES fetch 64 tasks and their
+//     four bitmap/offset words at once and park them in LDS; the MFMA operand lanes then pick their task's words from
+//     LDS and issue the value gathers of four pairs back to back;
+//   * the four levels of the chain belong to four DIFFERENT groups in any one iteration (group k: task_begin, k-1: tasks,
+//     k-2: bitmaps/offsets -> LDS, k-3: values + MFMA + store), so each iteration waits for one round trip, not four.
+// A group with more than 64 tasks (hub C blocks) streams its remaining 64-task windows through the same LDS slot unpipelined.
+constexpr int kGroupC = 16;
+
+struct MacMeta {
+    uint64_t abmp[64], bbmp[64], cbmp[kGroupC], coff[kGroupC];
+    uint32_t aoff[64], boff[64];
+};
+
+__global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_group_kernel(const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin,
+                                                                            const uint64_t *__restrict__ a_bmps, const uint64_t *__restrict__ a_offs,
+                                                                            const _Float16 *__restrict__ a_vals, const uint64_t *__restrict__ b_bmps,
+                                                                            const uint64_t *__restrict__ b_offs, const _Float16 *__restrict__ b_vals,
+                                                                            const uint64_t *__restrict__ c_bmps, const uint64_t *__restrict__ c_offs,
+                                                                            float *__restrict__ c_vals, uint32_t c_size, uint32_t a_bytes, uint32_t b_bytes)
+{
+    __shared__ MacMeta s_meta[4][2];
+    const int w = wave_id(), lane = lane_id();
+    const int line = lane & 7;          // tile row (A operand) / tile column (B operand)
+    const int which = (lane >> 3) & 1;  // which C block of the pair this lane feeds
+    const int kq = lane >> 4;
+    const int slot = kq >> 1, khalf = kq & 1;
+    const rsrc_t ra = make_rsrc(a_vals, a_bytes), rb = make_rsrc(b_vals, b_bytes);
+    const uint32_t groups = (c_size + kGroupC - 1) / kGroupC;
+    const uint32_t g0 = blockIdx.x * 4 + w, stride = gridDim.x * 4;
+    const uint32_t mine = g0 < groups ? (groups - g0 + stride - 1) / stride : 0u;
+    // task_begin words of the groups in stages 1..3 (lane l <= 16 holds task_begin[16 g + l]); 0 = no tasks
+    uint32_t tbv1 = 0, tbv2 = 0, tbv3 = 0;
+    uint64_t tk2 = 0;  // the task lane `lane` fetched for the group now entering stage 2
+    for (uint32_t k = 0; k < mine + 3; k++) {
+        // stage 0: task_begin of group k
+        uint32_t tbv0 = 0;
+        if (k < mine) tbv0 = task_begin[min((g0 + k * stride) * kGroupC + (uint32_t)min(lane, kGroupC), c_size)];
+        // stage 1: first 64 tasks of group k-1
+        uint64_t tk1 = 0;
+        {
+            const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)tbv1, 0), te = (uint32_t)__builtin_amdgcn_readlane((int)tbv1, kGroupC);
+            if (tb + lane < min(te, tb + 64u)) tk1 = tasks[tb + lane];
+        }
+        // stage 2: bitmaps / value offsets of those tasks for group k-2, C block bitmaps / offsets of the group
+        uint64_t m_abmp = 0, m_bbmp = 0, m_cbmp = 0, m_coff = 0;
+        uint32_t m_aoff = 0, m_boff = 0;
+        const bool have2 = k >= 2 && k - 2 < mine;
+        {
+            const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)tbv2, 0), te = (uint32_t)__builtin_amdgcn_readlane((int)tbv2, kGroupC);
+            if (tb + lane < min(te, tb + 64u)) {
+                const uint32_t a = (uint32_t)(tk2 >> 32), b = (uint32_t)tk2;
+                m_abmp = a_bmps[a]; m_aoff = (uint32_t)a_offs[a] * 2u;
+                m_bbmp = b_bmps[b]; m_boff = (uint32_t)b_offs[b] * 2u;
+            }
+            if (have2 && lane < kGroupC) {
+                const uint32_t cc = min((g0 + (k - 2) * stride) * kGroupC + (uint32_t)lane, c_size - 1);
+                m_cbmp = c_bmps[cc]; m_coff = c_offs[cc];
+            }
+        }
+        // stage 3: values, MFMA, store for group k-3
+        if (k >= 3) {
+            MacMeta &M = s_meta[w][(k - 3) & 1];
+            const uint32_t c0 = (g0 + (k - 3) * stride) * kGroupC;
+            uint32_t sb[kGroupC + 1];
+#pragma unroll
+            for (int i = 0; i <= kGroupC; i++) sb[i] = (uint32_t)__builtin_amdgcn_readlane((int)tbv3, i);
+            const uint32_t tb = sb[0], te = sb[kGroupC];
+            float4_t acc[kGroupC / 2];
+#pragma unroll
+            for (int p = 0; p < kGroupC / 2; p++) acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (uint32_t lo = tb; lo < te; lo += 64) {
+                const uint32_t hi = min(lo + 64u, te);
+                if (lo != tb) {  // hub group: later windows, fetched in place
+                    __builtin_amdgcn_wave_barrier();
+                    if (lo + lane < hi) {
+                        const uint64_t tk = tasks[lo + lane];
+                        const uint32_t a = (uint32_t)(tk >> 32), b = (uint32_t)tk;
+                        M.abmp[lane] = a_bmps[a]; M.aoff[lane] = (uint32_t)a_offs[a] * 2u;
+                        M.bbmp[lane] = b_bmps[b]; M.boff[lane] = (uint32_t)b_offs[b] * 2u;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // the part of every C block's list that lies in this 64-task window; two tasks per MFMA step
+                uint32_t steps[kGroupC / 2], max_steps = 0;
+#pragma unroll
+                for (int p = 0; p < kGroupC / 2; p++) {
+                    const uint32_t b0 = max(sb[2 * p], lo), e0 = min(sb[2 * p + 1], hi);
+                    const uint32_t b1 = max(sb[2 * p + 1], lo), e1 = min(sb[2 * p + 2], hi);
+                    const uint32_t n0 = e0 > b0 ? e0 - b0 : 0u, n1 = e1 > b1 ? e1 - b1 : 0u;
+                    steps[p] = (max(n0, n1) + 1) / 2;
+                    max_steps = max(max_steps, steps[p]);
+                }
+                for (uint32_t s = 0; s < max_steps; s++) {
+#pragma unroll
+                    for (int h = 0; h < kGroupC / 8; h++) {
+                        half4_t fa[4], fb[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int p = 4 * h + q;
+                            if (s < steps[p]) {
+                                const uint32_t bq = max(which ? sb[2 * p + 1] : sb[2 * p], lo), eq = min(which ? sb[2 * p + 2] : sb[2 * p + 1], hi);
+                                const uint32_t t = bq + 2 * s + slot;
+                                const bool live = t < eq;
+                                const uint32_t i = live ? t - lo : 0u;
+                                fa[q] = load_nibble(M.abmp[i], ra, M.aoff[i], line, khalf, live);
+                                fb[q] = load_nibble(M.bbmp[i], rb, M.boff[i], line, khalf, live);
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int p = 4 * h + q;
+                            if (s < steps[p]) acc[p] = __builtin_amdgcn_mfma_f32_16x16x16f16(fa[q], fb[q], acc[p], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // result: lane holds D[4*(lane>>4)+r][lane&15]; block 0 of a pair lives in rows/cols 0-7, block 1 in 8-15
+            const int col = lane & 15, rq = lane >> 4;
+            const int blk = col >> 3;
+            if ((rq >> 1) == blk) {
+#pragma unroll
+                for (int p = 0; p < kGroupC / 2; p++) {
+                    if (c0 + 2 * p + blk < c_size) {
+                        const uint64_t bmp_c = M.cbmp[2 * p + blk];
+                        const uint64_t off = M.coff[2 * p + blk];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int pos = ((rq & 1) * 4 + r) * 8 + (col & 7);
+                            if (tile_has(bmp_c, pos)) c_vals[off + tile_rank(bmp_c, pos)] = acc[p][r];
+                        }
+                    }
+                }
+            }
+        }
+        // hand the stage-2 words to the LDS slot stage 3 will read next iteration (the other slot was read above)
+        if (have2) {
+            MacMeta &N = s_meta[w][(k - 2) & 1];
+            N.abmp[lane] = m_abmp; N.aoff[lane] = m_aoff;
+            N.bbmp[lane] = m_bbmp; N.boff[lane] = m_boff;
+            if (lane < kGroupC) { N.cbmp[lane] = m_cbmp; N.coff[lane] = m_coff; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        tbv3 = tbv2; tbv2 = tbv1; tbv1 = tbv0;
+        tk2 = tk1;
+    }
+}
+
 template <typename T>
 void launch_mac_valu(const uint64_t *tasks, const uint32_t *task_begin, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C,
                      hipStream_t st)
@@ -457,15 +609,18 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
 
     // T_5: group the tasks by C key
     PingPong<uint64_t> kk{k0.p, k1.p}, vv{v0.p, v1.p};
-    // AUTO: the reference switches to its segmented sort above BORDER tasks (:963); here the global radix sort on the packed
-    // key is the faster of the two at every size measured so far, so AUTO always takes it
-    const bool segmented = mode == BMSP_SORT_SEGMENTED;
-    S->sort_path = segmented ? 1 : 0;
+    // The tasks leave the expansion grouped by block-row of A (A's blocks are key-ordered), so only the column bits need
+    // sorting inside each block-row segment.  The segmented sort keeps a whole segment in LDS (segsort.hip); it wins when
+    // segments are long enough to fill a wave yet none exceeds a workgroup's LDS (cage-like rows); tiny segments (banded)
+    // and hub rows (power-law) are faster through the global radix sort on the packed key.  AUTO decides on the average
+    // segment length -- the reference decides on the task count alone (:963) -- and falls back when a hub row shows up.
+    const uint64_t a_block_rows = (uint64_t)A->num_block_rows();
+    const uint64_t avg_seg = n_tasks / (a_block_rows ? a_block_rows : 1);
+    const bool try_segmented = mode == BMSP_SORT_SEGMENTED || (mode == BMSP_SORT_AUTO && avg_seg <= 2048);
+    S->sort_path = 0;
     if (n_tasks) {
-        if (segmented) {
-            // tasks are already grouped by block-row of A (A's blocks are key-ordered): only the column bits
-            // need sorting inside each block-row segment
-            segsort_tasks_by_column(kk, vv, n_tasks, jbits, ibits, st);
+        if (try_segmented && segsort_tasks_by_column(kk, vv, n_tasks, jbits, st)) {
+            S->sort_path = 1;
             tm.mark(8);
         } else {
             device_radix_sort_pairs<uint64_t>(kk, vv, n_tasks, 0, ibits + jbits, st);
@@ -511,11 +666,19 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         if (mfma) {
             if ((uint64_t)A->nnz * 2 >= (1ull << 32) || (uint64_t)B->nnz * 2 >= (1ull << 32))
                 fail(BMSP_ERR_LIMIT, "MFMA block-MAC addresses operand values through 4 GiB buffer descriptors; use tc_version 5");
-            uint32_t groups = ((c_size + 1) / 2 + kPairsPerWave - 1) / kPairsPerWave;
-            uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
-            hipLaunchKernelGGL(block_mac_mfma_f16_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->bmps, A->offsets,
-                               (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
-                               (float *)C->values, c_size, (uint32_t)(A->nnz * 2), (uint32_t)(B->nnz * 2));
+            if (tc_version == 4) {
+                uint32_t groups = (c_size + kGroupC - 1) / kGroupC;
+                uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
+                hipLaunchKernelGGL(block_mac_mfma_f16_group_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->bmps, A->offsets,
+                                   (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
+                                   (float *)C->values, c_size, (uint32_t)(A->nnz * 2), (uint32_t)(B->nnz * 2));
+            } else {
+                uint32_t groups = ((c_size + 1) / 2 + kPairsPerWave - 1) / kPairsPerWave;
+                uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
+                hipLaunchKernelGGL(block_mac_mfma_f16_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->bmps, A->offsets,
+                                   (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
+                                   (float *)C->values, c_size, (uint32_t)(A->nnz * 2), (uint32_t)(B->nnz * 2));
+            }
             BMSP_CHECK_LAUNCH();
             S->mac_kernel = tc_version;
         } else {
@@ -537,7 +700,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         print_stage(true, "T_3", S->t_us[3]);
         printf("Bmp reduction: %lld\n", (long long)S->bmp_reduction);
         print_stage(true, "T_4", S->t_us[4]);
-        if (segmented) print_stage(true, "Segmented sort", S->t_us[8]);
+        if (S->sort_path == 1) print_stage(true, "Segmented sort", S->t_us[8]);
         print_stage(true, "T_5", S->t_us[5]);
         print_stage(true, "T_6", S->t_us[6]);
         print_stage(true, "T_9", S->t_us[9]);

@@ -371,13 +371,32 @@ def test_spgemm_properties_large(bmsp):
         np.testing.assert_allclose(vv, ref.data[order], rtol=1e-5, atol=1e-7)
 
 
+def _segsort_cuts(shape, rng, n):
+    """segment starts exercising each length bin of the device sort (wave <= 256, workgroup <= 4096, radix fallback)."""
+    if shape == "mixed":      # lengths 1 .. ~600, plus empty-adjacent and unit segments
+        extra = [5, 6, 7, 8, 100000, 100001]
+        return np.unique(np.concatenate([[0], rng.integers(0, n, 3000), extra]))
+    if shape == "tiny":       # lengths 1 .. 4
+        return np.unique(np.concatenate([[0], np.cumsum(rng.integers(1, 5, n))]))[:-1].clip(0, n - 1)
+    if shape == "block":      # bin edges 256/257, 4095/4096 and the power-of-two paddings in between
+        lens = [256, 257, 4096, 4095, 511, 512, 513, 1024, 1025, 2048, 2049, 3000, 300, 2, 1, 1, 255]
+        starts = np.concatenate([[0], np.cumsum(lens)])
+        return np.unique(np.concatenate([starts, np.arange(starts[-1], n, 3500)]))
+    if shape == "long":       # one hub segment: whole call takes the radix fallback
+        return np.unique(np.concatenate([[0, 10, 50000], rng.integers(50000, n, 500)]))
+    raise ValueError(shape)
+
+
+@pytest.mark.parametrize("shape", ["mixed", "tiny", "block", "long"])
 @pytest.mark.parametrize("val_bytes", [0, 4, 8, 16])
-def test_segsort_against_gold(oracle, bmsp, val_bytes):
+def test_segsort_against_gold(oracle, bmsp, val_bytes, shape):
     rng = np.random.default_rng(val_bytes)
     n = 200000
     keys = rng.integers(0, 1 << 40, n).astype(np.uint64)
     keys[: n // 2] &= np.uint64(0xFF)  # many ties: stability matters
-    cuts = np.unique(np.concatenate([[0], rng.integers(0, n, 3000), [5, 6, 7, 8, 100000, 100001]])).astype(np.int64)
+    keys[n // 2: n // 2 + 3000] = np.uint64(0xFFFFFFFFFFFFFFFF)  # equal to the padding sentinel of the LDS network
+    cuts = np.unique(_segsort_cuts(shape, rng, n)).astype(np.int64)
+    cuts = cuts[cuts < n]
     pay = np.stack([np.arange(n, dtype=np.uint64), keys ^ np.uint64(0xABCDEF)], axis=1)
     gk, gv = oracle.segsort(keys, pay, cuts)
     dk = bmsp.DeviceArray.from_host(keys)
