@@ -28,6 +28,9 @@ struct bmsp_matrix_s {
     // a row-panel view points into its parent
     int64_t view_block_begin = 0;
 
+    int64_t view_values_end = 0;  // row-panel views: end (in elements) of the panel's values inside the parent's array
+    // elements addressable from `values`: offsets of a view stay absolute into the parent's value array
+    int64_t values_extent() const { return view_values_end ? view_values_end : nnz; }
     int64_t num_block_rows() const { return ((int64_t)num_rows + 7) / 8; }
     int64_t num_block_cols() const { return ((int64_t)num_cols + 7) / 8; }
 };

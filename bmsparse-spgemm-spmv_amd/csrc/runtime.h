@@ -33,6 +33,7 @@ void set_last_error(const std::string &msg);
 
 // Pooled device allocations.  hipMalloc/hipFree synchronise the device; the SpGEMM pipeline needs a dozen
 // temporaries per call, so freed blocks are kept (bucketed by rounded size) and handed out again.
+constexpr size_t kPoolSlack = 64;
 void *pool_alloc(size_t bytes);
 void pool_free(void *p);
 void pool_trim();

@@ -47,7 +47,9 @@ size_t round_size(size_t b)
 
 void *pool_alloc(size_t bytes)
 {
-    size_t r = round_size(bytes);
+    // every block carries kPoolSlack readable bytes past the requested size: kernels that fetch a tile's values with one wide
+    // load may touch (and discard) up to 12 bytes beyond the last stored value
+    size_t r = round_size(bytes + kPoolSlack);
     Pool &P = pool();
     {
         std::lock_guard<std::mutex> lk(P.mu);

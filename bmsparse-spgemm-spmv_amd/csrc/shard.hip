@@ -80,6 +80,7 @@ bmsp_matrix_s *row_panel(bmsp_matrix_s *m, int64_t rb, int64_t re, hipStream_t s
     v->values = m->values;  // offsets stay absolute into the parent's value array
     v->ownership = 2;
     v->view_block_begin = b0;
+    v->view_values_end = (int64_t)o1;
     return v;
 }
 

@@ -303,6 +303,56 @@ __device__ __forceinline__ half4_t load_nibble(uint64_t bmp, rsrc_t vals, uint32
     return r;
 }
 
+// Wide variant: the (up to four) stored values of a nibble are consecutive halves, so ONE 12-byte load from the enclosing
+// aligned dwords fetches them all; a funnel shift drops the odd leading half and v_perm_b32 routes value `rank` to lane slot
+// `q` (or zero) with a selector looked up by nibble pattern.  ~10 VALU + 3 VMEM fewer than load_nibble per operand.
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+
+struct NibbleLane {   // per-lane constants of the operand position p0 = line*8 + khalf*4
+    uint32_t use_hi;  // the nibble lives in the high word of the bitmap
+    uint32_t shift;   // its shift inside that word
+    uint32_t hi_mask, lo_mask;  // bitmap bits of positions < p0
+};
+__device__ __forceinline__ NibbleLane make_nibble_lane(int line, int khalf)
+{
+    const uint32_t p0 = (uint32_t)(line * 8 + khalf * 4);
+    NibbleLane n;
+    n.use_hi = p0 < 32u;
+    n.shift = (60u - p0) & 31u;
+    n.hi_mask = p0 >= 32u ? 0xffffffffu : (p0 == 0u ? 0u : 0xffffffffu << (32u - p0));
+    n.lo_mask = p0 > 32u ? 0xffffffffu << (64u - p0) : 0u;
+    return n;
+}
+// selector pair for nibble pattern `nib` (bit 3 = first position): output half q takes stored value popc(bits before q)
+__device__ __forceinline__ uint64_t nibble_selector(uint32_t nib)
+{
+    uint64_t sel = 0;
+    uint32_t rank = 0;
+    for (int q = 0; q < 4; q++) {
+        const bool has = (nib >> (3 - q)) & 1u;
+        const uint64_t two = has ? (uint64_t)((2u * rank) | ((2u * rank + 1u) << 8)) : 0x0c0cull;
+        sel |= two << (16 * q);
+        rank += has;
+    }
+    return sel;
+}
+__device__ __forceinline__ half4_t load_nibble_wide(uint64_t bmp, rsrc_t vals, uint32_t tile_byte_off, const NibbleLane &n, const uint64_t *sel_table, bool live)
+{
+    const uint32_t hi = (uint32_t)(bmp >> 32), lo = (uint32_t)bmp;
+    const uint32_t nib = live ? ((n.use_hi ? hi : lo) >> n.shift) & 0xfu : 0u;
+    const uint32_t rank = (uint32_t)__builtin_popcount(hi & n.hi_mask) + (uint32_t)__builtin_popcount(lo & n.lo_mask);
+    const uint32_t addr = tile_byte_off + rank * 2u;
+    const u32x3_t d = __builtin_amdgcn_raw_buffer_load_b96(vals, nib ? (addr & ~3u) : kOob, 0, 0);
+    const uint64_t sel = sel_table[nib];
+    const uint32_t sh = (addr & 2u) * 8u;
+    const uint32_t v01 = __builtin_amdgcn_alignbit(d[1], d[0], sh), v23 = __builtin_amdgcn_alignbit(d[2], d[1], sh);
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t r;
+    r[0] = __builtin_amdgcn_perm(v23, v01, (uint32_t)sel);
+    r[1] = __builtin_amdgcn_perm(v23, v01, (uint32_t)(sel >> 32));
+    return __builtin_bit_cast(half4_t, r);
+}
+
 constexpr int kPairsPerWave = 4;  // C-block pairs a wave works on at once (independent load chains in flight)
 
 __global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_kernel(const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin,
@@ -402,11 +452,16 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_group_kernel(cons
                                                                             float *__restrict__ c_vals, uint32_t c_size, uint32_t a_bytes, uint32_t b_bytes)
 {
     __shared__ MacMeta s_meta[4][2];
+    __shared__ float s_out[4][kGroupC][64];  // finished C tiles, position-major, before the compacting store
+    __shared__ uint64_t s_sel[16];
     const int w = wave_id(), lane = lane_id();
     const int line = lane & 7;          // tile row (A operand) / tile column (B operand)
     const int which = (lane >> 3) & 1;  // which C block of the pair this lane feeds
     const int kq = lane >> 4;
     const int slot = kq >> 1, khalf = kq & 1;
+    const NibbleLane nl = make_nibble_lane(line, khalf);
+    if (threadIdx.x < 16) s_sel[threadIdx.x] = nibble_selector(threadIdx.x);
+    __syncthreads();
     const rsrc_t ra = make_rsrc(a_vals, a_bytes), rb = make_rsrc(b_vals, b_bytes);
     const uint32_t groups = (c_size + kGroupC - 1) / kGroupC;
     const uint32_t g0 = blockIdx.x * 4 + w, stride = gridDim.x * 4;
@@ -485,8 +540,8 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_group_kernel(cons
                                 const uint32_t t = bq + 2 * s + slot;
                                 const bool live = t < eq;
                                 const uint32_t i = live ? t - lo : 0u;
-                                fa[q] = load_nibble(M.abmp[i], ra, M.aoff[i], line, khalf, live);
-                                fb[q] = load_nibble(M.bbmp[i], rb, M.boff[i], line, khalf, live);
+                                fa[q] = load_nibble_wide(M.abmp[i], ra, M.aoff[i], nl, s_sel, live);
+                                fb[q] = load_nibble_wide(M.bbmp[i], rb, M.boff[i], nl, s_sel, live);
                             }
                         }
 #pragma unroll
@@ -497,21 +552,32 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_group_kernel(cons
                     }
                 }
             }
-            // result: lane holds D[4*(lane>>4)+r][lane&15]; block 0 of a pair lives in rows/cols 0-7, block 1 in 8-15
+            // result: lane holds D[4*(lane>>4)+r][lane&15]; block 0 of a pair lives in rows/cols 0-7, block 1 in 8-15.  The
+            // tiles go through LDS into position-per-lane form: lane = tile position, so the rank of a position inside the
+            // C bitmap is one mbcnt against the bit-reversed (wave-uniform) bitmap and each C block is one contiguous store.
             const int col = lane & 15, rq = lane >> 4;
             const int blk = col >> 3;
             if ((rq >> 1) == blk) {
 #pragma unroll
                 for (int p = 0; p < kGroupC / 2; p++) {
-                    if (c0 + 2 * p + blk < c_size) {
-                        const uint64_t bmp_c = M.cbmp[2 * p + blk];
-                        const uint64_t off = M.coff[2 * p + blk];
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int pos = ((rq & 1) * 4 + r) * 8 + (col & 7);
-                            if (tile_has(bmp_c, pos)) c_vals[off + tile_rank(bmp_c, pos)] = acc[p][r];
-                        }
-                    }
+                    for (int r = 0; r < 4; r++) s_out[w][2 * p + blk][((rq & 1) * 4 + r) * 8 + (col & 7)] = acc[p][r];
+                }
+            }
+            const uint64_t my_cbmp = M.cbmp[lane & (kGroupC - 1)], my_coff = M.coff[lane & (kGroupC - 1)];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < kGroupC; j++) {
+                if (c0 + j < c_size) {
+                    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_cbmp, j);
+                    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_cbmp >> 32), j);
+                    const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_coff >> 32), j) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_coff, j);
+                    // position `lane` is bit 63-lane of the bitmap = bit `lane` of its reversal
+                    const uint32_t rlo = __builtin_bitreverse32(bhi), rhi = __builtin_bitreverse32(blo);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(rhi, __builtin_amdgcn_mbcnt_lo(rlo, 0u));
+                    const uint32_t word = lane < 32 ? rlo : rhi;
+                    if ((word >> (lane & 31)) & 1u) (c_vals + off)[rank] = s_out[w][j][lane];
                 }
             }
         }
@@ -664,20 +730,23 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     // T_7: block multiply-accumulate
     if (c_size) {
         if (mfma) {
-            if ((uint64_t)A->nnz * 2 >= (1ull << 32) || (uint64_t)B->nnz * 2 >= (1ull << 32))
+            if ((uint64_t)A->values_extent() * 2 + 16 >= (1ull << 32) || (uint64_t)B->values_extent() * 2 + 16 >= (1ull << 32))
                 fail(BMSP_ERR_LIMIT, "MFMA block-MAC addresses operand values through 4 GiB buffer descriptors; use tc_version 5");
-            if (tc_version == 4) {
+            // the group kernel's 12-byte value loads may run past the last stored value: arrays from this library's
+            // allocator carry that slack (runtime.h), borrowed arrays (bmsp_matrix_from_arrays, ownership 2) may not
+            const uint32_t a_bytes = (uint32_t)(A->values_extent() * 2), b_bytes = (uint32_t)(B->values_extent() * 2);
+            if (tc_version == 4 && pool_owns(A->values) && pool_owns(B->values)) {
                 uint32_t groups = (c_size + kGroupC - 1) / kGroupC;
                 uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
                 hipLaunchKernelGGL(block_mac_mfma_f16_group_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->bmps, A->offsets,
                                    (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
-                                   (float *)C->values, c_size, (uint32_t)(A->nnz * 2), (uint32_t)(B->nnz * 2));
+                                   (float *)C->values, c_size, a_bytes + 16u, b_bytes + 16u);
             } else {
                 uint32_t groups = ((c_size + 1) / 2 + kPairsPerWave - 1) / kPairsPerWave;
                 uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
                 hipLaunchKernelGGL(block_mac_mfma_f16_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->bmps, A->offsets,
                                    (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
-                                   (float *)C->values, c_size, (uint32_t)(A->nnz * 2), (uint32_t)(B->nnz * 2));
+                                   (float *)C->values, c_size, a_bytes, b_bytes);
             }
             BMSP_CHECK_LAUNCH();
             S->mac_kernel = tc_version;

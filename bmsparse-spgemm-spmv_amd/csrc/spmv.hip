@@ -423,7 +423,7 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
         hipLaunchKernelGGL((spmv_blockrow_kernel<T, 8>), dim3((nbr + 31) / 32), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps,
                            A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows,
                            (uint32_t)A->num_cols, nbr);
-    } else if ((size_t)A->nnz * sizeof(T) >= (1ull << 32) || (size_t)A->num_cols * sizeof(T) >= (1ull << 32)) {
+    } else if ((size_t)A->values_extent() * sizeof(T) >= (1ull << 32) || (size_t)A->num_cols * sizeof(T) >= (1ull << 32)) {
         // buffer descriptors address 4 GiB; beyond that fall back to the pointer-based block-row kernel
         hipLaunchKernelGGL((spmv_blockrow_kernel<T, 64>), dim3((nbr + 3) / 4), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps,
                            A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows,
@@ -435,7 +435,7 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
         hipLaunchKernelGGL((spmv_sweep_kernel<T>), dim3((n_items + 3) / 4), dim3(kThreads), 0, st, (const SweepItem *)(mem + 64), n_items,
                            A->keys, A->bmps, A->offsets, (const T *)A->values, (const T *)v, (Ac *)u,
                            (Ac *)(mem + A->spmv_plan_off_carry), (uint32_t *)(mem + A->spmv_plan_off_cnt), (uint32_t)A->num_rows,
-                           (uint32_t)A->num_cols, (uint32_t)((size_t)A->nnz * sizeof(T)));
+                           (uint32_t)A->num_cols, (uint32_t)((size_t)A->values_extent() * sizeof(T)));
     }
     BMSP_CHECK_LAUNCH();
 }

@@ -239,6 +239,14 @@ class BmSpMatrix:
             d.release()
         return BmSpMatrix(h.value)
 
+    @staticmethod
+    def from_device_arrays(num_rows, num_cols, keys, bmps, offsets, values, dtype=F32, transposed=False):
+        """borrows DeviceArrays (ownership 2): `offsets` must hold block_num+1 entries; the arrays must outlive the matrix."""
+        h = C.c_void_p()
+        check(lib().bmsp_matrix_from_arrays(int(num_rows), int(num_cols), keys.n, values.n, keys.ptr, bmps.ptr, offsets.ptr, values.ptr, dtype,
+                                            int(bool(transposed)), 2, C.byref(h)))
+        return BmSpMatrix(h.value, parent=(keys, bmps, offsets, values))
+
     def save(self, path):
         check(lib().bmsp_matrix_save(self.h, os.fsencode(path)))
 

@@ -457,6 +457,53 @@ def test_row_panels_concat_equals_whole(oracle, bmsp):
             np.testing.assert_array_equal(x, y)
 
 
+def test_row_panel_views_fp16_mfma_and_spmv(oracle, bmsp):
+    """a panel view keeps absolute offsets into its parent's value array: the buffer-addressed kernels (MFMA block-MAC, sweep
+    SpMV) must size their descriptors by the parent's extent, not by the panel's nnz."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(11, 6)
+    v = np.round(v * 4) / 4  # fp16-exact inputs
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=bmsp.F16)
+    Bt = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=bmsp.F16)
+    for tc in (4, 3):
+        whole, _ = bmsp.spgemm(A, Bt, tc_version=tc)
+        bounds = bmsp.partition_rows(A, Bt, 3)
+        panels, keep = [], []
+        for p in range(3):
+            view = A.row_panel(bounds[p], bounds[p + 1])
+            Cp, _ = bmsp.spgemm(view, Bt, tc_version=tc)
+            keep.append((view, Cp))
+            panels.append(Cp.device_arrays())
+        cat = bmsp.concat_panels(n, n, panels)
+        for x, y in zip(cat.host_arrays(), whole.host_arrays()):
+            np.testing.assert_array_equal(x, y)
+    Af = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    x = bmsp.DeviceArray.from_host(gen.spmv_x(n, "cusp"))
+    y = bmsp.spmv(Af, x).to_host()
+    nbr = (n + 7) // 8
+    lo, hi = nbr // 3, 2 * nbr // 3
+    view = Af.row_panel(lo, hi)
+    yp = bmsp.spmv(view, x).to_host()
+    np.testing.assert_array_equal(yp[lo * 8: hi * 8], y[lo * 8: hi * 8])
+    assert not yp[: lo * 8].any() and not yp[hi * 8:].any()
+
+
+def test_borrowed_arrays_multiply(oracle, bmsp):
+    """bmsp_matrix_from_arrays with ownership 2 (caller keeps the arrays), every MAC kernel."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(10, 5)
+    v = np.round(v * 4) / 4
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=bmsp.F16)
+    Bt = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=bmsp.F16)
+    A2 = bmsp.BmSpMatrix.from_device_arrays(n, n, *A.device_arrays(), dtype=bmsp.F16)
+    B2 = bmsp.BmSpMatrix.from_device_arrays(n, n, *Bt.device_arrays(), dtype=bmsp.F16, transposed=True)
+    for tc in (5, 4, 2):
+        ref, _ = bmsp.spgemm(A, Bt, tc_version=tc)
+        got, _ = bmsp.spgemm(A2, B2, tc_version=tc)
+        for x, y in zip(got.host_arrays(), ref.host_arrays()):
+            np.testing.assert_array_equal(x, y)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # drop-in executables and batch scripts (boundary: argv + stdout contract, SURVEY.md Appendix B)
 # ---------------------------------------------------------------------------------------------------------
