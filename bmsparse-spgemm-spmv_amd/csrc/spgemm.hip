@@ -430,27 +430,32 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_kernel(const uint
 // The kernel above walks each C block's task list with the whole wave, so a wave has one dependent chain
 // (task_begin -> task -> bitmaps/offsets -> values) per C-block pair in flight and the stage is bound by memory round trips
 // (profiles/r01c_spgemm_cage_like_summary.md: 59 % of wave cycles parked on s_waitcnt at 4.5 waves/SIMD).  Here a wave
-// owns 16 consecutive C blocks (8 MFMA pairs) per step and turns the chain sideways:
+// owns kGroupC consecutive C blocks (kGroupC/2 MFMA pairs) per step and turns the chain sideways:
 //   * the tasks of those blocks are one contiguous range of the sorted task list, so 64 LANES fetch 64 tasks and their
 //     four bitmap/offset words at once and park them in LDS; the MFMA operand lanes then pick their task's words from
 //     LDS and issue the value gathers of four pairs back to back;
 //   * the four levels of the chain belong to four DIFFERENT groups in any one iteration (group k: task_begin, k-1: tasks,
 //     k-2: bitmaps/offsets -> LDS, k-3: values + MFMA + store), so each iteration waits for one round trip, not four.
 // A group with more than 64 tasks (hub C blocks) streams its remaining 64-task windows through the same LDS slot unpipelined.
-constexpr int kGroupC = 16;
 
+template <int kGroupC>
 struct MacMeta {
     uint64_t abmp[64], bbmp[64], cbmp[kGroupC], coff[kGroupC];
     uint32_t aoff[64], boff[64];
 };
 
-__global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_group_kernel(const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin,
-                                                                            const uint64_t *__restrict__ a_bmps, const uint64_t *__restrict__ a_offs,
-                                                                            const _Float16 *__restrict__ a_vals, const uint64_t *__restrict__ b_bmps,
-                                                                            const uint64_t *__restrict__ b_offs, const _Float16 *__restrict__ b_vals,
-                                                                            const uint64_t *__restrict__ c_bmps, const uint64_t *__restrict__ c_offs,
-                                                                            float *__restrict__ c_vals, uint32_t c_size, uint32_t a_bytes, uint32_t b_bytes)
+#define BMSP_MAC_ARGS                                                                                                              \
+    const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin, const uint64_t *__restrict__ a_bmps,                  \
+        const uint64_t *__restrict__ a_offs, const _Float16 *__restrict__ a_vals, const uint64_t *__restrict__ b_bmps,                 \
+        const uint64_t *__restrict__ b_offs, const _Float16 *__restrict__ b_vals, const uint64_t *__restrict__ c_bmps,                 \
+        const uint64_t *__restrict__ c_offs, float *__restrict__ c_vals, uint32_t c_size, uint32_t a_bytes, uint32_t b_bytes
+#define BMSP_MAC_PASS tasks, task_begin, a_bmps, a_offs, a_vals, b_bmps, b_offs, b_vals, c_bmps, c_offs, c_vals, c_size, a_bytes, b_bytes
+
+template <int kGroupC>
+__device__ __forceinline__ void block_mac_group_body(BMSP_MAC_ARGS)
 {
+    typedef MacMeta<kGroupC> MacMeta;
+    constexpr int kPairs = kGroupC / 2, kBatch = kPairs < 4 ? kPairs : 4;  // pairs whose value gathers are issued back to back
     __shared__ MacMeta s_meta[4][2];
     __shared__ float s_out[4][kGroupC][64];  // finished C tiles, position-major, before the compacting store
     __shared__ uint64_t s_sel[16];
@@ -530,11 +535,11 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_group_kernel(cons
                 }
                 for (uint32_t s = 0; s < max_steps; s++) {
 #pragma unroll
-                    for (int h = 0; h < kGroupC / 8; h++) {
-                        half4_t fa[4], fb[4];
+                    for (int h = 0; h < kPairs / kBatch; h++) {
+                        half4_t fa[kBatch], fb[kBatch];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int p = 4 * h + q;
+                        for (int q = 0; q < kBatch; q++) {
+                            const int p = kBatch * h + q;
                             if (s < steps[p]) {
                                 const uint32_t bq = max(which ? sb[2 * p + 1] : sb[2 * p], lo), eq = min(which ? sb[2 * p + 2] : sb[2 * p + 1], hi);
                                 const uint32_t t = bq + 2 * s + slot;
@@ -545,8 +550,8 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_group_kernel(cons
                             }
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int p = 4 * h + q;
+                        for (int q = 0; q < kBatch; q++) {
+                            const int p = kBatch * h + q;
                             if (s < steps[p]) acc[p] = __builtin_amdgcn_mfma_f32_16x16x16f16(fa[q], fb[q], acc[p], 0, 0, 0);
                         }
                     }
@@ -592,6 +597,14 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma_f16_group_kernel(cons
         tbv3 = tbv2; tbv2 = tbv1; tbv1 = tbv0;
         tk2 = tk1;
     }
+}
+
+// Group size 4 (two MFMA pairs per step, 68 VGPRs, 7 waves/SIMD) measured best of {16, 8, 4, 2} x occupancy caps on the three
+// generator cases (block-MAC log): larger groups fetch more per round trip but halve the resident waves.
+constexpr int kGroupC = 4;
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void block_mac_mfma_f16_group_kernel(BMSP_MAC_ARGS)
+{
+    block_mac_group_body<kGroupC>(BMSP_MAC_PASS);
 }
 
 template <typename T>
