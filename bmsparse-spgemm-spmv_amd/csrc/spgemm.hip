@@ -607,16 +607,169 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 8))
     block_mac_group_body<kGroupC>(BMSP_MAC_PASS);
 }
 
+// ---- T_7, vector-ALU numerics on the group schedule ---------------------------------------------------------------
+// Same software pipeline as the MFMA group kernel (task_begin / tasks / bitmaps+offsets of the next groups are in flight
+// while the current group computes), V15 numerics of block_mac_valu_kernel: lane l owns C(l/8, l%8) and adds the eight
+// products of a task in k order, tasks in list order.  Per task the two tiles are expanded position-per-lane -- the
+// task's bitmap is wave-uniform, so a lane's value index is one mbcnt against the reversed bitmap -- and staged through
+// LDS; value loads of kValuBatch consecutive tasks (across C-block boundaries) are issued before the first is consumed.
+constexpr int kValuGroupC = 8;
+constexpr int kValuBatch = 4;
+
+template <typename T>
+struct ValuLoad;
+template <>
+struct ValuLoad<float> {
+    static __device__ __forceinline__ float ld(rsrc_t r, uint32_t off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
+};
+template <>
+struct ValuLoad<_Float16> {
+    static __device__ __forceinline__ _Float16 ld(rsrc_t r, uint32_t off) { return ld_half(r, off); }
+};
+template <>
+struct ValuLoad<double> {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ double ld(rsrc_t r, uint32_t off) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); }
+};
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+}
+// position `lane` of a tile is bit 63-lane of its bitmap = bit `lane` of the reversed bitmap; rank = set positions before it
+__device__ __forceinline__ bool tile_lane(uint64_t bmp_uniform, int lane, uint32_t &rank)
+{
+    const uint32_t rlo = __builtin_bitreverse32((uint32_t)(bmp_uniform >> 32)), rhi = __builtin_bitreverse32((uint32_t)bmp_uniform);
+    rank = __builtin_amdgcn_mbcnt_hi(rhi, __builtin_amdgcn_mbcnt_lo(rlo, 0u));
+    return ((lane < 32 ? rlo : rhi) >> (lane & 31)) & 1u;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin,
+                                                                        const uint64_t *__restrict__ a_bmps, const uint64_t *__restrict__ a_offs,
+                                                                        const T *__restrict__ a_vals, const uint64_t *__restrict__ b_bmps,
+                                                                        const uint64_t *__restrict__ b_offs, const T *__restrict__ b_vals,
+                                                                        const uint64_t *__restrict__ c_bmps, const uint64_t *__restrict__ c_offs,
+                                                                        typename MacOps<T>::Out *__restrict__ c_vals, uint32_t c_size, uint32_t a_bytes,
+                                                                        uint32_t b_bytes)
+{
+    using O = typename MacOps<T>::Out;
+    constexpr int G = kValuGroupC, U = kValuBatch;
+    __shared__ __attribute__((aligned(16))) T tile_a[4][U][64];
+    __shared__ __attribute__((aligned(16))) T tile_b[4][U][64];
+    const int w = wave_id(), lane = lane_id();
+    const int i = lane >> 3, j = lane & 7;
+    const rsrc_t ra = make_rsrc(a_vals, a_bytes), rb = make_rsrc(b_vals, b_bytes);
+    const uint32_t groups = (c_size + G - 1) / G;
+    const uint32_t g0 = blockIdx.x * 4 + w, stride = gridDim.x * 4;
+    const uint32_t mine = g0 < groups ? (groups - g0 + stride - 1) / stride : 0u;
+    uint32_t tbv1 = 0, tbv2 = 0, tbv3 = 0;  // lane l <= G holds task_begin[G g + l] of the group in stage 1 / 2 / 3
+    uint64_t tk2 = 0;
+    // stage-3 inputs, fetched one iteration earlier: lane l holds the words of task tb + l, lane l < G those of C block l
+    uint64_t w_abmp = 0, w_bbmp = 0, w_cbmp = 0, w_coff = 0;
+    uint32_t w_aoff = 0, w_boff = 0;
+    for (uint32_t k = 0; k < mine + 3; k++) {
+        uint32_t tbv0 = 0;
+        if (k < mine) tbv0 = task_begin[min((g0 + k * stride) * G + (uint32_t)min(lane, G), c_size)];
+        uint64_t tk1 = 0;
+        {
+            const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)tbv1, 0), te = (uint32_t)__builtin_amdgcn_readlane((int)tbv1, G);
+            if (tb + lane < min(te, tb + 64u)) tk1 = tasks[tb + lane];
+        }
+        uint64_t m_abmp = 0, m_bbmp = 0, m_cbmp = 0, m_coff = 0;
+        uint32_t m_aoff = 0, m_boff = 0;
+        {
+            const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)tbv2, 0), te = (uint32_t)__builtin_amdgcn_readlane((int)tbv2, G);
+            if (tb + lane < min(te, tb + 64u)) {
+                const uint32_t a = (uint32_t)(tk2 >> 32), b = (uint32_t)tk2;
+                m_abmp = a_bmps[a]; m_aoff = (uint32_t)a_offs[a] * (uint32_t)sizeof(T);
+                m_bbmp = b_bmps[b]; m_boff = (uint32_t)b_offs[b] * (uint32_t)sizeof(T);
+            }
+            if (k >= 2 && k - 2 < mine && lane < G) {
+                const uint32_t cc = min((g0 + (k - 2) * stride) * G + (uint32_t)lane, c_size - 1);
+                m_cbmp = c_bmps[cc]; m_coff = c_offs[cc];
+            }
+        }
+        if (k >= 3) {
+            const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)tbv3, 0), te = (uint32_t)__builtin_amdgcn_readlane((int)tbv3, G);
+            uint32_t c_cur = 0, cur_end = (uint32_t)__builtin_amdgcn_readlane((int)tbv3, 1), win_lo = tb;
+            O acc = 0;
+            for (uint32_t t = tb; t < te; t += U) {
+                if (t >= win_lo + 64u) {  // hub group: next 64-task window, fetched in place
+                    win_lo = t;
+                    w_abmp = 0; w_bbmp = 0; w_aoff = 0; w_boff = 0;
+                    if (t + lane < te) {
+                        const uint64_t tk = tasks[t + lane];
+                        const uint32_t a = (uint32_t)(tk >> 32), b = (uint32_t)tk;
+                        w_abmp = a_bmps[a]; w_aoff = (uint32_t)a_offs[a] * (uint32_t)sizeof(T);
+                        w_bbmp = b_bmps[b]; w_boff = (uint32_t)b_offs[b] * (uint32_t)sizeof(T);
+                    }
+                }
+                T av[U], bv[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t l = min(t + u - win_lo, 63u);
+                    const bool on = t + u < te;
+                    uint32_t rka, rkb;
+                    const bool ha = tile_lane(readlane_u64(w_abmp, l), lane, rka) && on;
+                    const bool hb = tile_lane(readlane_u64(w_bbmp, l), lane, rkb) && on;
+                    const uint32_t oa = (uint32_t)__builtin_amdgcn_readlane((int)w_aoff, (int)l), ob = (uint32_t)__builtin_amdgcn_readlane((int)w_boff, (int)l);
+                    av[u] = ValuLoad<T>::ld(ra, ha ? oa + rka * (uint32_t)sizeof(T) : kOob);
+                    bv[u] = ValuLoad<T>::ld(rb, hb ? ob + rkb * (uint32_t)sizeof(T) : kOob);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    tile_a[w][u][lane] = av[u];  // A(i,k) at i*8+k
+                    tile_b[w][u][lane] = bv[u];  // B column-major in the tile: B(k,j) at j*8+k
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (t + u < te) {
+                        if (t + u >= cur_end) {  // the list of C block c_cur is exhausted: compacting store, next block
+                            uint32_t rk;
+                            if (tile_lane(readlane_u64(w_cbmp, c_cur), lane, rk)) (c_vals + readlane_u64(w_coff, c_cur))[rk] = acc;
+                            acc = 0;
+                            c_cur++;
+                            cur_end = (uint32_t)__builtin_amdgcn_readlane((int)tbv3, (int)(c_cur + 1));
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++) acc = MacOps<T>::step(tile_a[w][u][i * 8 + kk], tile_b[w][u][j * 8 + kk], acc);
+                    }
+                }
+            }
+            if (te > tb) {
+                uint32_t rk;
+                if (tile_lane(readlane_u64(w_cbmp, c_cur), lane, rk)) (c_vals + readlane_u64(w_coff, c_cur))[rk] = acc;
+            }
+        }
+        w_abmp = m_abmp; w_bbmp = m_bbmp; w_cbmp = m_cbmp; w_coff = m_coff;
+        w_aoff = m_aoff; w_boff = m_boff;
+        tbv3 = tbv2; tbv2 = tbv1; tbv1 = tbv0;
+        tk2 = tk1;
+    }
+}
+
 template <typename T>
 void launch_mac_valu(const uint64_t *tasks, const uint32_t *task_begin, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C,
                      hipStream_t st)
 {
     uint32_t cs = (uint32_t)C->block_num;
     if (!cs) return;
-    uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)cs + 3) / 4, 256ull * 64);
-    hipLaunchKernelGGL((block_mac_valu_kernel<T>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin, A->bmps, A->offsets,
-                       (const T *)A->values, B->bmps, B->offsets, (const T *)B->values, C->bmps, C->offsets,
-                       (typename MacOps<T>::Out *)C->values, cs);
+    const uint64_t a_bytes = (uint64_t)A->values_extent() * sizeof(T), b_bytes = (uint64_t)B->values_extent() * sizeof(T);
+    if (a_bytes < (1ull << 32) && b_bytes < (1ull << 32)) {
+        const uint32_t groups = (cs + kValuGroupC - 1) / kValuGroupC;
+        uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
+        hipLaunchKernelGGL((block_mac_valu_group_kernel<T>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin, A->bmps, A->offsets,
+                           (const T *)A->values, B->bmps, B->offsets, (const T *)B->values, C->bmps, C->offsets,
+                           (typename MacOps<T>::Out *)C->values, cs, (uint32_t)a_bytes, (uint32_t)b_bytes);
+    } else {  // value arrays beyond the 4 GiB a buffer descriptor addresses: pointer-based kernel
+        uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)cs + 3) / 4, 256ull * 64);
+        hipLaunchKernelGGL((block_mac_valu_kernel<T>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin, A->bmps, A->offsets,
+                           (const T *)A->values, B->bmps, B->offsets, (const T *)B->values, C->bmps, C->offsets,
+                           (typename MacOps<T>::Out *)C->values, cs);
+    }
     BMSP_CHECK_LAUNCH();
 }
 
