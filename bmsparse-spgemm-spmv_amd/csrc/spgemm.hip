@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 8))
 // products of a task in k order, tasks in list order.  Per task the two tiles are expanded position-per-lane -- the
 // task's bitmap is wave-uniform, so a lane's value index is one mbcnt against the reversed bitmap -- and staged through
 // LDS; value loads of kValuBatch consecutive tasks (across C-block boundaries) are issued before the first is consumed.
-constexpr int kValuGroupC = 8;
+constexpr int kValuGroupC = 16;  // (16, 4) measured best of G in {4,8,16,32} x U in {2,4,8} on the generator cases
 constexpr int kValuBatch = 4;
 
 template <typename T>
@@ -644,7 +644,7 @@ __device__ __forceinline__ bool tile_lane(uint64_t bmp_uniform, int lane, uint32
     return ((lane < 32 ? rlo : rhi) >> (lane & 31)) & 1u;
 }
 
-template <typename T>
+template <typename T, int G, int U>
 __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin,
                                                                         const uint64_t *__restrict__ a_bmps, const uint64_t *__restrict__ a_offs,
                                                                         const T *__restrict__ a_vals, const uint64_t *__restrict__ b_bmps,
@@ -654,7 +654,6 @@ __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const ui
                                                                         uint32_t b_bytes)
 {
     using O = typename MacOps<T>::Out;
-    constexpr int G = kValuGroupC, U = kValuBatch;
     __shared__ __attribute__((aligned(16))) T tile_a[4][U][64];
     __shared__ __attribute__((aligned(16))) T tile_b[4][U][64];
     const int w = wave_id(), lane = lane_id();
@@ -761,8 +760,8 @@ void launch_mac_valu(const uint64_t *tasks, const uint32_t *task_begin, bmsp_mat
     if (a_bytes < (1ull << 32) && b_bytes < (1ull << 32)) {
         const uint32_t groups = (cs + kValuGroupC - 1) / kValuGroupC;
         uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
-        hipLaunchKernelGGL((block_mac_valu_group_kernel<T>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin, A->bmps, A->offsets,
-                           (const T *)A->values, B->bmps, B->offsets, (const T *)B->values, C->bmps, C->offsets,
+        hipLaunchKernelGGL((block_mac_valu_group_kernel<T, kValuGroupC, kValuBatch>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin, A->bmps,
+                           A->offsets, (const T *)A->values, B->bmps, B->offsets, (const T *)B->values, C->bmps, C->offsets,
                            (typename MacOps<T>::Out *)C->values, cs, (uint32_t)a_bytes, (uint32_t)b_bytes);
     } else {  // value arrays beyond the 4 GiB a buffer descriptor addresses: pointer-based kernel
         uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)cs + 3) / 4, 256ull * 64);
