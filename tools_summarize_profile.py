@@ -3,17 +3,24 @@
 import csv, glob, collections, os, shutil, sys
 
 src, tag, kern = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "spmv_sweep")
+cmd = sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --skip-cpu --skip-spgemm --steps 100 --warmup 10"
 os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))
 lines = ["# rocprofv3 summary `%s` (source: %s)" % (tag, src), "",
-         "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --skip-cpu --skip-spgemm --steps 100 --warmup 10`"
-         " and, in separate runs, `rocprofv3 --pmc <counters>` with the same command.", ""]
+         "command: `rocprofv3 --kernel-trace --stats --output-format csv -- %s` and, in separate runs, "
+         "`rocprofv3 --pmc <counters>` with the same command." % cmd, ""]
 if stats:
     shutil.copy(stats[0], "profiles/%s_kernel_stats.csv" % tag)
     lines += ["## kernel-trace --stats (top kernels)", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
     for i, row in enumerate(csv.DictReader(open(stats[0]))):
-        if i >= 8: break
-        lines.append("| %s | %s | %.0f | %s | %s | %s |" % (row["Name"].split("(")[0][-70:], row["Calls"], float(row["AverageNs"]), row["MinNs"], row["MaxNs"], row["Percentage"]))
+        if i >= 14: break
+        nm = row["Name"]
+        if nm.startswith("_Z"):  # left mangled by the tool: keep the readable middle
+            import re
+            m = re.search(r"\d+([a-z_0-9]+_kernel)", nm)
+            nm = m.group(1) if m else nm[:60]
+        nm = nm.replace("void ", "").replace("bmsp::(anonymous namespace)::", "").replace("bmsp::", "").split("(")[0][:80]
+        lines.append("| %s | %s | %.0f | %s | %s | %s |" % (nm, row["Calls"], float(row["AverageNs"]), row["MinNs"], row["MaxNs"], row["Percentage"]))
 lines += ["", "## PMC counters of `%s` (average per dispatch)" % kern, "", "| pass | counter | value |", "|---|---|---|"]
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d): continue
@@ -25,9 +32,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         a = agg[row["Counter_Name"]]; a[0] += 1; a[1] += float(row["Counter_Value"])
     for c, (n, s) in sorted(agg.items()):
         lines.append("| %s | %s | %.1f |" % (os.path.basename(d), c, s / n))
-lines += ["", "Notes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads "
-          "(MI355X_MICROARCH.md, HBM section) -- the correction factor for this kernel's 8-byte-per-lane streams and 4-byte gathers is "
-          "uncalibrated, so `traffic` lies between FETCH_SIZE and 2 x FETCH_SIZE.", ""]
+lines += ["", "Notes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request "
+          "(MI355X_MICROARCH.md, HBM section; experiments/fetch_calib.hip confirms the factor 2 for 8- and 16-byte-per-lane streams and for "
+          "4-byte gathers).", ""]
 # HBM traffic of the kernel per launch, corrected as MI355X_MICROARCH.md prescribes and as experiments/fetch_calib.hip confirms for
 # this kernel's access shapes (8-byte-per-lane streams and 4-byte gathers both count 64 B per 128-B request): 2 x FETCH_SIZE + WRITE_SIZE
 import json
