@@ -464,13 +464,14 @@ struct Iota32 {
 };
 }  // namespace
 
-void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st)
+// every stored value as ((row << 32) | col, value), sorted by (row, col); both outputs hold nnz entries
+void matrix_to_coo_device(bmsp_matrix_s *m, uint64_t *d_rc, double *d_vals, hipStream_t st)
 {
     uint64_t n = (uint64_t)m->nnz;
     if (n == 0) return;
     DevBuf<uint64_t> k0(n), k1(n);
     DevBuf<uint32_t> p0(n), p1(n);
-    DevBuf<double> v0(n), v1(n);
+    DevBuf<double> v0(n);
     uint64_t nb = (uint64_t)m->block_num;
     if (m->dtype == BMSP_F32)
         device_for_each(ExpandBlocks<float>{m->keys, m->bmps, m->offsets, (const float *)m->values, m->transposed, k0.p, v0.p}, nb, st);
@@ -485,15 +486,93 @@ void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hi
     // sort by column bits, then by row bits (stable LSD): row-major order
     device_radix_sort_pairs<uint32_t>(kk, pp, n, 0, cb, st);
     device_radix_sort_pairs<uint32_t>(kk, pp, n, 32, 32 + rb, st);
-    device_for_each(GatherD{v0.p, pp.cur, v1.p}, n, st);
+    device_for_each(GatherD{v0.p, pp.cur, d_vals}, n, st);
+    BMSP_HIP(hipMemcpyAsync(d_rc, kk.cur, 8 * n, hipMemcpyDeviceToDevice, st));
+    BMSP_HIP(hipStreamSynchronize(st));
+}
+
+void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st)
+{
+    uint64_t n = (uint64_t)m->nnz;
+    if (n == 0) return;
+    DevBuf<uint64_t> rc(n);
+    DevBuf<double> v(n);
+    matrix_to_coo_device(m, rc.p, v.p, st);
     std::vector<uint64_t> hk(n);
-    BMSP_HIP(hipMemcpyAsync(hk.data(), kk.cur, 8 * n, hipMemcpyDeviceToHost, st));
-    BMSP_HIP(hipMemcpyAsync(vals, v1.p, 8 * n, hipMemcpyDeviceToHost, st));
+    BMSP_HIP(hipMemcpyAsync(hk.data(), rc.p, 8 * n, hipMemcpyDeviceToHost, st));
+    BMSP_HIP(hipMemcpyAsync(vals, v.p, 8 * n, hipMemcpyDeviceToHost, st));
     BMSP_HIP(hipStreamSynchronize(st));
     for (uint64_t i = 0; i < n; i++) {
         rows[i] = (int)(hk[i] >> 32);
         cols[i] = (int)(hk[i] & 0xffffffffull);
     }
+}
+
+namespace {
+struct SplitRowCol {
+    const uint64_t *rc;
+    int *rows, *cols;
+    __device__ void operator()(uint64_t i) const
+    {
+        if (rows) rows[i] = (int)(rc[i] >> 32);
+        cols[i] = (int)(rc[i] & 0xffffffffull);
+    }
+};
+// row_offsets[r] = index of the first entry whose row is >= r, from the (row, col)-sorted list
+struct RowOffsetsFromSorted {
+    const uint64_t *rc;
+    uint64_t n;
+    uint32_t num_rows;
+    int *row_offsets;
+    __device__ void operator()(uint64_t i) const
+    {
+        const uint32_t hi = i < n ? (uint32_t)(rc[i] >> 32) : num_rows;
+        const uint32_t lo = i ? (uint32_t)(rc[i - 1] >> 32) + 1u : 0u;
+        for (uint32_t r = lo; r <= hi; r++) row_offsets[r] = (int)i;
+    }
+};
+struct RowOfEntry {
+    const int *row_offsets;
+    uint32_t num_rows;
+    int *rows;
+    __device__ void operator()(uint64_t i) const
+    {
+        uint32_t lo = 0, hi = num_rows;  // last r with row_offsets[r] <= i
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint64_t)row_offsets[mid] <= i) lo = mid; else hi = mid;
+        }
+        rows[i] = (int)lo;
+    }
+};
+}  // namespace
+
+void matrix_to_coo_device_split(bmsp_matrix_s *m, int *d_rows, int *d_cols, double *d_vals, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)m->nnz;
+    if (!n) return;
+    DevBuf<uint64_t> rc(n);
+    matrix_to_coo_device(m, rc.p, d_vals, st);
+    device_for_each(SplitRowCol{rc.p, d_rows, d_cols}, n, st);
+    BMSP_HIP(hipStreamSynchronize(st));
+}
+
+void matrix_to_csr_device(bmsp_matrix_s *m, int *d_row_offsets, int *d_cols, double *d_vals, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)m->nnz;
+    DevBuf<uint64_t> rc(n);
+    matrix_to_coo_device(m, rc.p, d_vals, st);
+    device_for_each(RowOffsetsFromSorted{rc.p, n, (uint32_t)m->num_rows, d_row_offsets}, n + 1, st);
+    if (n) device_for_each(SplitRowCol{rc.p, nullptr, d_cols}, n, st);
+    BMSP_HIP(hipStreamSynchronize(st));
+}
+
+bmsp_matrix_s *build_from_device_csr(int num_rows, int num_cols, int64_t nnz, const int *d_row_offsets, const int *d_cols, const double *d_vals,
+                                     int transposed, bmsp_dtype dtype, hipStream_t st)
+{
+    DevBuf<int> rows((size_t)nnz);
+    if (nnz) device_for_each(RowOfEntry{d_row_offsets, (uint32_t)num_rows, rows.p}, (uint64_t)nnz, st);
+    return build_from_device_coo(num_rows, num_cols, nnz, rows.p, d_cols, d_vals, transposed, dtype, st);
 }
 
 }  // namespace bmsp

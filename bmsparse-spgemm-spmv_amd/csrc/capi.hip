@@ -366,6 +366,37 @@ int bmsp_matrix_to_coo_host(bmsp_matrix_t m, int *rows, int *cols, double *vals)
     BMSP_API_END
 }
 
+int bmsp_matrix_to_coo_device(bmsp_matrix_t m, int *d_rows, int *d_cols, double *d_vals, void *stream)
+{
+    BMSP_API_BEGIN
+    need(m, "matrix");
+    if (m->nnz) { need(d_rows, "rows"); need(d_cols, "cols"); need(d_vals, "vals"); }
+    if (m->ownership == 2 && m->view_block_begin) fail(BMSP_ERR_UNSUPPORTED, "row-panel views cannot be expanded; expand the parent");
+    matrix_to_coo_device_split(m, d_rows, d_cols, d_vals, as_stream(stream));
+    BMSP_API_END
+}
+
+int bmsp_matrix_to_csr_device(bmsp_matrix_t m, int *d_row_offsets, int *d_cols, double *d_vals, void *stream)
+{
+    BMSP_API_BEGIN
+    need(m, "matrix"); need(d_row_offsets, "row_offsets");
+    if (m->nnz) { need(d_cols, "cols"); need(d_vals, "vals"); }
+    if (m->ownership == 2 && m->view_block_begin) fail(BMSP_ERR_UNSUPPORTED, "row-panel views cannot be expanded; expand the parent");
+    matrix_to_csr_device(m, d_row_offsets, d_cols, d_vals, as_stream(stream));
+    BMSP_API_END
+}
+
+int bmsp_matrix_from_csr_device(int num_rows, int num_cols, int64_t nnz, const int *d_row_offsets, const int *d_cols, const double *d_vals,
+                                int transposed, bmsp_dtype dtype, void *stream, bmsp_matrix_t *out)
+{
+    BMSP_API_BEGIN
+    need(out, "out"); need(d_row_offsets, "row_offsets");
+    if (num_rows < 0 || num_cols < 0 || nnz < 0) fail(BMSP_ERR_INVALID, "negative size");
+    if (nnz) { need(d_cols, "cols"); need(d_vals, "vals"); }
+    *out = build_from_device_csr(num_rows, num_cols, nnz, d_row_offsets, d_cols, d_vals, transposed, dtype, as_stream(stream));
+    BMSP_API_END
+}
+
 int bmsp_matrix_compare(bmsp_matrix_t m, int64_t nnz, const int *rows, const int *cols, const double *vals, double *mean_rel_err,
                         int64_t *missing)
 {
@@ -405,6 +436,16 @@ int bmsp_spmv(bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *st
     BMSP_API_BEGIN
     need(A, "A");
     spmv(A, d_v, d_u, variant, as_stream(stream));
+    BMSP_API_END
+}
+
+int bmsp_spmm(bmsp_matrix_t A, const void *d_X, int64_t ldx, void *d_Y, int64_t ldy, int k, void *stream)
+{
+    BMSP_API_BEGIN
+    need(A, "A");
+    if (A->num_cols) need(d_X, "X");
+    if (A->num_rows) need(d_Y, "Y");
+    spmm(A, d_X, ldx, d_Y, ldy, k, as_stream(stream));
     BMSP_API_END
 }
 

@@ -56,9 +56,14 @@ bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, co
 
 void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st);
 void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st);
+void matrix_to_coo_device_split(bmsp_matrix_s *m, int *d_rows, int *d_cols, double *d_vals, hipStream_t st);
+void matrix_to_csr_device(bmsp_matrix_s *m, int *d_row_offsets, int *d_cols, double *d_vals, hipStream_t st);
+bmsp_matrix_s *build_from_device_csr(int num_rows, int num_cols, int64_t nnz, const int *d_row_offsets, const int *d_cols, const double *d_vals,
+                                     int transposed, bmsp_dtype dtype, hipStream_t st);
 void free_matrix(bmsp_matrix_s *m);
 
 void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st);
+void spmm(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, int k, hipStream_t st);
 void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int tc_version, int verbose, hipStream_t st,
             bmsp_spgemm_stats *stats);
 template <typename T>

@@ -29,30 +29,12 @@
 // variant 1 ("batched"): a whole wave sweeps one block-row, 8 tiles x 8 tile rows per step, and folds the eight partial
 //     rows with xor-shuffles (wavefront reduction): contiguous value loads per tile, for matrices with dense tiles.
 // variant 2: 8-lane group per block-row (kept for comparison).
-#include "matrix.h"
+#include "spmv_plan.h"
 #include "prims.hip.h"
 #include <cstdlib>
 
 namespace bmsp {
 namespace {
-
-template <typename T>
-struct Acc { using type = float; };
-template <>
-struct Acc<double> { using type = double; };
-
-constexpr uint32_t kItemTiles = 256;  // tile budget of an item (short items hold < 2x this, long-row items exactly this)
-constexpr uint32_t kBatch = 128;      // tiles a wave loads at once (two per lane)
-constexpr uint32_t kItemRows = 16;    // block-rows per item window (u tile = 16 x 8 accumulators)
-
-struct SweepItem {      // 32 bytes, read with scalar loads
-    uint32_t row_begin, row_end;  // block-rows [row_begin, row_end)
-    uint32_t blk_begin, blk_end;  // tiles [blk_begin, blk_end)
-    uint32_t first_item;          // long rows: index of the row's first item
-    uint32_t num_items;           // long rows: number of items of the row; 0 = short item
-    uint32_t long_idx;            // long rows: arrival counter index
-    uint32_t pad;
-};
 
 // ---------------------------------------------------------------------------------------------------------
 // plan construction (once per matrix)
@@ -128,6 +110,8 @@ struct SweepPlan {
     uint32_t *counters;  // num_long arrival counters, zero between calls
 };
 
+}  // namespace
+
 void build_plan(bmsp_matrix_s *A, hipStream_t st)
 {
     if (A->spmv_chunks) return;
@@ -155,6 +139,8 @@ void build_plan(bmsp_matrix_s *A, hipStream_t st)
     A->spmv_plan_off_cnt = off_cnt;
     A->spmv_plan_off_carry = off_carry;
 }
+
+namespace {
 
 // ---------------------------------------------------------------------------------------------------------
 // the sweep kernel

@@ -27,7 +27,7 @@ SYMBOLS = [
     "bmsp_event_create", "bmsp_event_record", "bmsp_event_elapsed_ms", "bmsp_event_destroy",
     "bmsp_matrix_from_mtx", "bmsp_matrix_from_coo", "bmsp_matrix_from_coo_device", "bmsp_matrix_from_arrays",
     "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
-    "bmsp_matrix_to_coo_host", "bmsp_matrix_compare", "bmsp_spmv", "bmsp_spgemm", "bmsp_segsort_u64",
+    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_spmv", "bmsp_spmm", "bmsp_spgemm", "bmsp_segsort_u64",
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
     "bmsp_csr_spmv", "bmsp_csr_free",
@@ -91,8 +91,12 @@ def lib():
         L.bmsp_matrix_arrays.argtypes = [vp, p(vp), p(vp), p(vp), p(vp)]
         L.bmsp_matrix_block_row_ptr.argtypes = [vp, p(vp), p(i64)]
         L.bmsp_matrix_to_coo_host.argtypes = [vp, vp, vp, vp]
+        L.bmsp_matrix_to_coo_device.argtypes = [vp, vp, vp, vp, vp]
+        L.bmsp_matrix_to_csr_device.argtypes = [vp, vp, vp, vp, vp]
+        L.bmsp_matrix_from_csr_device.argtypes = [i, i, i64, vp, vp, vp, i, i, vp, p(vp)]
         L.bmsp_matrix_compare.argtypes = [vp, i64, vp, vp, vp, p(C.c_double), p(i64)]
         L.bmsp_spmv.argtypes = [vp, vp, vp, i, vp]
+        L.bmsp_spmm.argtypes = [vp, vp, i64, vp, i64, i, vp]
         L.bmsp_spgemm.argtypes = [vp, vp, p(vp), i, i, i, vp, p(SpgemmStats)]
         L.bmsp_segsort_u64.argtypes = [vp, vp, i, i64, vp, i64, vp]
         L.bmsp_partition_rows.argtypes = [vp, vp, i, vp]
@@ -293,6 +297,27 @@ class BmSpMatrix:
         check(lib().bmsp_matrix_to_coo_host(self.h, r.ctypes.data, c.ctypes.data, v.ctypes.data))
         return r, c, v
 
+    def to_coo_device(self, stream=None):
+        """(rows int32, cols int32, vals float64) DeviceArrays, sorted by (row, col)."""
+        n = self.nnz
+        r, c, v = DeviceArray(n, np.int32), DeviceArray(n, np.int32), DeviceArray(n, np.float64)
+        check(lib().bmsp_matrix_to_coo_device(self.h, r.ptr, c.ptr, v.ptr, stream))
+        return r, c, v
+
+    def to_csr_device(self, stream=None):
+        """(row_offsets int32 [num_rows+1], cols int32, vals float64) DeviceArrays."""
+        i = self.info()
+        ro, c, v = DeviceArray(i["num_rows"] + 1, np.int32), DeviceArray(i["nnz"], np.int32), DeviceArray(i["nnz"], np.float64)
+        check(lib().bmsp_matrix_to_csr_device(self.h, ro.ptr, c.ptr, v.ptr, stream))
+        return ro, c, v
+
+    @staticmethod
+    def from_csr_device(num_rows, num_cols, row_offsets, cols, vals, transposed=False, dtype=F32, stream=None):
+        h = C.c_void_p()
+        check(lib().bmsp_matrix_from_csr_device(int(num_rows), int(num_cols), cols.n, row_offsets.ptr, cols.ptr, vals.ptr,
+                                                int(bool(transposed)), dtype, stream, C.byref(h)))
+        return BmSpMatrix(h.value)
+
     # compare(coo)
     def compare(self, rows, cols, vals):
         rows = np.ascontiguousarray(rows, dtype=np.int32)
@@ -328,6 +353,17 @@ def spmv(A, v, u=None, batched=False, stream=None):
         u = DeviceArray(i["num_rows"], OUT_DTYPE[i["dtype"]])
     check(lib().bmsp_spmv(A.h, v.ptr, u.ptr, SPMV_BATCHED if batched else SPMV_DEFAULT, stream))
     return u
+
+
+def spmm(A, X, k, Y=None, ldx=None, ldy=None, stream=None):
+    """X: DeviceArray holding num_cols x k row-major (A's dtype); returns Y (num_rows x k, float32 / float64 for F64)."""
+    i = A.info()
+    ldx = k if ldx is None else ldx
+    ldy = k if ldy is None else ldy
+    if Y is None:
+        Y = DeviceArray(i["num_rows"] * ldy, OUT_DTYPE[i["dtype"]])
+    check(lib().bmsp_spmm(A.h, X.ptr, int(ldx), Y.ptr, int(ldy), int(k), stream))
+    return Y
 
 
 # bmSparse_mult(A, B, C, mode, VERBOSE, tc_version)

@@ -228,6 +228,14 @@ template <class ValueIn, class ValueOut> inline void bmSparse_SpMV(bmSpMatrix<Va
     bmsp::check(bmsp_synchronize());
 }
 
+/* Multi-vector form: U = A * V for k vectors, V row-major num_cols x k, U row-major num_rows x k. */
+template <class ValueIn, class ValueOut> inline void bmSparse_SpMM(bmSpMatrix<ValueIn> &A, ValueIn *V, ValueOut *U, int k)
+{
+    static_assert(std::is_same<ValueOut, float>::value || std::is_same<ValueOut, double>::value, "U is float (double for double input)");
+    bmsp::check(bmsp_spmm(A.handle(), V, k, U, k, k, nullptr));
+    bmsp::check(bmsp_synchronize());
+}
+
 /* src/bmSparse_SPGEMM.cu:827-1223.  `mode` is the reference's `segmented` flag (declared bool there). */
 template <class valueIn, class valueOut>
 inline void bmSparse_mult(bmSpMatrix<valueIn> &A, bmSpMatrix<valueIn> &B, bmSpMatrix<valueOut> &C, bool mode, bool VERBOSE, long tc_version,

@@ -118,6 +118,14 @@ int bmsp_matrix_block_row_ptr(bmsp_matrix_t m, const uint32_t **d_rowptr, int64_
  * rows/cols/vals must hold nnz entries.  Unlike the reference it honours the transposed layout. */
 int bmsp_matrix_to_coo_host(bmsp_matrix_t m, int *rows, int *cols, double *vals);
 
+/* SURVEY 8(f)2 -- the same expansion with the result left on the device, as COO or CSR sorted by (row, col), so a product can
+ * feed CSR consumers without a host round trip.  d_rows/d_cols/d_vals hold nnz entries, d_row_offsets num_rows+1. */
+int bmsp_matrix_to_coo_device(bmsp_matrix_t m, int *d_rows, int *d_cols, double *d_vals, void *stream);
+int bmsp_matrix_to_csr_device(bmsp_matrix_t m, int *d_row_offsets, int *d_cols, double *d_vals, void *stream);
+/* ... and the builder from a device-resident CSR (int32 offsets/columns, float64 values; duplicates summed as in from_coo). */
+int bmsp_matrix_from_csr_device(int num_rows, int num_cols, int64_t nnz, const int *d_row_offsets, const int *d_cols,
+                                const double *d_vals, int transposed, bmsp_dtype dtype, void *stream, bmsp_matrix_t *out);
+
 /* bmSpMatrix<T>::compare(coo)  -- src/bmSpMatrix.cu:381-432.  Mean relative error against a host COO
  * comparand (entries of the comparand that are absent from m are skipped).  *missing counts entries of m
  * that the comparand lacks (the reference would walk out of bounds). */
@@ -136,6 +144,11 @@ int bmsp_matrix_compare(bmsp_matrix_t m, int64_t nnz, const int *rows, const int
  * v: device, num_cols entries of A's dtype; u: device, num_rows entries (float for F32/F16, double for F64).
  * Asynchronous on `stream`; A is not modified.  Rows of empty block-rows are written as 0. */
 int bmsp_spmv(bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *stream);
+
+/* SURVEY 8(f)3 -- Y = A * X for k vectors at once (what the reference's unfinished `batched` path points at,
+ * src/bmSparse_SPMV.cu:84-150,191).  X is row-major num_cols x k with leading dimension ldx (elements of A's dtype),
+ * Y row-major num_rows x k with leading dimension ldy (float, double for F64): one pass over A's tiles for all k. */
+int bmsp_spmm(bmsp_matrix_t A, const void *d_X, int64_t ldx, void *d_Y, int64_t ldy, int k, void *stream);
 
 /* per-stage figures of one product: the lines the reference prints when VERBOSE
  * (src/bmSparse_SPGEMM.cu:849-1220) plus what the roofline needs. */

@@ -488,6 +488,70 @@ def test_row_panel_views_fp16_mfma_and_spmv(oracle, bmsp):
     assert not yp[: lo * 8].any() and not yp[hi * 8:].any()
 
 
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_device_coo_csr_conversions(oracle, bmsp, dtype):
+    """bmSparse -> COO / CSR on the device and back, against scipy's CSR of the same triples."""
+    import scipy.sparse as sp
+    from pybmsp import gen
+    n, m = 1237, 911  # ragged last block row and column, empty rows in between
+    rng = np.random.default_rng(7 + dtype)
+    nnz = 9000
+    r = rng.integers(0, n, nnz).astype(np.int32); c = rng.integers(0, m, nnz).astype(np.int32)
+    r[r % 17 == 3] = 5  # a hub row, and rows == 3 (mod 17) left empty
+    v = np.round(rng.standard_normal(nnz) * 8) / 8
+    ref = sp.coo_matrix((v, (r, c)), shape=(n, m)).tocsr()
+    ref.sum_duplicates(); ref.sort_indices()
+    for transposed in (False, True):
+        M = bmsp.BmSpMatrix.from_coo(n, m, r, c, v, transposed=transposed, dtype=dtype)
+        ro, cc, vv = (a.to_host() for a in M.to_csr_device())
+        np.testing.assert_array_equal(ro, ref.indptr)
+        np.testing.assert_array_equal(cc, ref.indices)
+        np.testing.assert_array_equal(vv, ref.data)
+        rr, c2, v2 = (a.to_host() for a in M.to_coo_device())
+        np.testing.assert_array_equal(rr, np.repeat(np.arange(n), np.diff(ref.indptr)))
+        np.testing.assert_array_equal(c2, ref.indices); np.testing.assert_array_equal(v2, ref.data)
+        # back: CSR on the device -> bmSparse, identical arrays
+        M2 = bmsp.BmSpMatrix.from_csr_device(n, m, *M.to_csr_device(), transposed=transposed, dtype=dtype)
+        for x, y in zip(M2.host_arrays(), M.host_arrays()):
+            np.testing.assert_array_equal(x, y)
+    E = bmsp.BmSpMatrix.from_coo(5, 5, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), dtype=dtype)
+    np.testing.assert_array_equal(E.to_csr_device()[0].to_host(), np.zeros(6, np.int32))
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("k", [1, 3, 4, 8, 16, 17, 64, 100])
+def test_spmm_against_scipy(oracle, bmsp, dtype, k):
+    """Y = A X for k vectors.  The reference has no running multi-vector path (parity unpinned against it):
+    checked against scipy in float64 with the SpMV tolerance, and column by column against single-vector calls."""
+    import scipy.sparse as sp
+    from pybmsp import gen
+    np_in = bmsp.NP_DTYPE[dtype]; np_out = bmsp.OUT_DTYPE[dtype]
+    cases = [gen.rmat(11, 8), gen.banded(1003, 5)]  # hub block-rows (carry path) / ragged last block, regular rows
+    for (n, _, r, c, v) in cases:
+        v = np.round(v * 8) / 8
+        A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=dtype)
+        ref = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsr()
+        rng = np.random.default_rng(k)
+        X = (np.round(rng.standard_normal((n, k)) * 4) / 4).astype(np_in)
+        Y = bmsp.spmm(A, bmsp.DeviceArray.from_host(X.reshape(-1)), k).to_host().reshape(n, k)
+        assert Y.dtype == np_out
+        want = ref @ X.astype(np.float64)
+        mag = abs(ref) @ abs(X.astype(np.float64))
+        tol = 1e-5 if dtype != 1 else 2e-3
+        assert np.all(np.abs(Y - want) <= tol * mag + 1e-6)
+        # a column of the k-wide product equals the one-vector product (inputs are exact in the accumulator, so any order agrees)
+        if k in (3, 17):
+            for jj in (0, k - 1):
+                y1 = bmsp.spmm(A, bmsp.DeviceArray.from_host(np.ascontiguousarray(X[:, jj])), 1).to_host()
+                np.testing.assert_array_equal(y1, Y[:, jj])
+        # strided operands
+        if k == 8:
+            ldx, ldy = 11, 9
+            Xs = np.zeros((n, ldx), np_in); Xs[:, :k] = X
+            Ys = bmsp.spmm(A, bmsp.DeviceArray.from_host(Xs.reshape(-1)), k, ldx=ldx, ldy=ldy).to_host().reshape(n, ldy)
+            np.testing.assert_array_equal(Ys[:, :k], Y)
+
+
 def test_borrowed_arrays_multiply(oracle, bmsp):
     """bmsp_matrix_from_arrays with ownership 2 (caller keeps the arrays), every MAC kernel."""
     from pybmsp import gen
