@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--batched", type=int, default=-1, help="-1 auto, 0 / 1 force the SpMV variant")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-spgemm", action="store_true")
+    ap.add_argument("--skip-vendor", action="store_true", help="skip the rocSPARSE comparison column")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
@@ -184,6 +185,13 @@ def main():
     if use_dist and not args.skip_spgemm:
         out["spgemm_sharded"] = bench_spgemm_sharded(B, gen, np, torch, dist, rank, world)
 
+    # ---------------- vendor comparison column (rocSPARSE CSR on the same matrices; reporting only) ----------------
+    if rank == 0 and not use_dist and not args.skip_vendor:
+        try:
+            out["vendor"] = vendor_column(np, gen, wl, eff_bytes, args)
+        except Exception as e:  # the column is optional: never let it take the bench line down
+            out["vendor"] = {"error": str(e)[:200]}
+
     # ---------------- CPU baseline (cusp::multiply restatement) on rank 0, N = 1 only ----------------
     if rank == 0 and not use_dist and not args.skip_cpu:
         out["cpu_baseline"] = cpu_baseline(wl, eff_bytes, args)
@@ -230,6 +238,50 @@ def bench_spgemm(B, gen, np, args):
                     "sort_path": "segmented" if best["sort_path"] else "global radix",
                     "roofline": {"bound": "mfma" if dtype == B.F16 else "valu", "kernel": "block_mac", "achieved": round(f_mac / t_mac / 1e12, 3),
                                  "peak": peak, "unit": "TFLOP/s", "frac": round(f_mac / t_mac / 1e12 / peak, 5), "traffic": None}})
+    return res
+
+
+def vendor_column(np, gen, wl, eff_bytes, args):
+    """rocSPARSE CSR SpMV / SpGEMM (fp32) on the bench matrices, cache-warm like `warm_ms_per_step`."""
+    import ctypes as C
+    import scipy.sparse as sp
+    so = os.path.join(REPO, "vendor_compare", "librocsparse_ref.so")
+    if not os.path.exists(so):
+        return {"error": "vendor_compare/librocsparse_ref.so not built"}
+    V = C.CDLL(so)
+    vp, i64, dp = C.c_void_p, C.c_int64, C.POINTER(C.c_double)
+    V.vendor_csr_spmv.argtypes = [C.c_int, C.c_int, i64, vp, vp, vp, vp, vp, C.c_int, C.c_int, dp, dp]
+    V.vendor_csr_spgemm.argtypes = [C.c_int, C.c_int, C.c_int, i64, vp, vp, vp, i64, vp, vp, vp, C.c_int, dp, dp, C.POINTER(i64), dp]
+
+    def csr_of(coo):
+        n, _, r, c, v = coo
+        m = sp.coo_matrix((v.astype(np.float32), (r, c)), shape=(n, n)).tocsr()
+        m.sum_duplicates(); m.sort_indices()
+        return m, m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32)
+
+    res = {"library": "rocSPARSE (ROCm 7.2), CSR fp32 int32 indices; same matrices, cache-warm timing"}
+    if "coo" in wl:
+        m, ptr, col, val = csr_of(wl["coo"])
+        x = np.ones(m.shape[1], np.float32); y = np.zeros(m.shape[0], np.float32)
+        best = None
+        for alg, name in ((0, "default"), (1, "adaptive"), (2, "rowsplit"), (3, "lrb")):
+            ms, pre = C.c_double(), C.c_double()
+            rc = V.vendor_csr_spmv(m.shape[0], m.shape[1], m.nnz, ptr.ctypes.data, col.ctypes.data, val.ctypes.data, x.ctypes.data, y.ctypes.data,
+                                   alg, 200, C.byref(ms), C.byref(pre))
+            if rc == 0 and (best is None or ms.value < best[1]):
+                best = (name, ms.value, pre.value)
+        if best:
+            res["spmv"] = {"alg": best[0], "ms": round(best[1], 5), "preprocess_ms": round(best[2], 3),
+                           "effective_GBs": round(eff_bytes / (best[1] * 1e-3) / 1e9, 1), "y_checksum": float(y.sum())}
+    if not args.skip_spgemm:
+        res["spgemm"] = []
+        for name, coo in (("2cubes_sphere-like banded(101492, half_bw=8)", gen.banded(101492, 8)), ("cage12-like local+random(130228, 15.6/row)", gen.cage_like(130228, 15.6))):
+            m, ptr, col, val = csr_of(coo)
+            ms, first, nz, sm = C.c_double(), C.c_double(), i64(), C.c_double()
+            rc = V.vendor_csr_spgemm(m.shape[0], m.shape[1], m.shape[1], m.nnz, ptr.ctypes.data, col.ctypes.data, val.ctypes.data, m.nnz, ptr.ctypes.data,
+                                     col.ctypes.data, val.ctypes.data, 5, C.byref(ms), C.byref(first), C.byref(nz), C.byref(sm))
+            res["spgemm"].append({"workload": "CSR SpGEMM A*A fp32, " + name, "rc": rc, "ms": round(ms.value, 3), "first_call_ms": round(first.value, 3),
+                                  "c_nnz": nz.value})
     return res
 
 
