@@ -89,13 +89,25 @@ __global__ __launch_bounds__(kThreads) void scan_tile_down_kernel(In in, Out out
     for (uint64_t t = 0; t < tiles_per_block; t++) {
         uint64_t base = (first_tile + t) * kTile;
         if (base >= n) break;
-        for (int k = 0; k < kItems; k++) {
-            uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
-            T v = i < n ? in(i) : T(0);
-            T total;
-            T ex = block_exclusive_sum(v, lds, total);
-            if (i < n) out(i, carry + ex);
-            carry += total;
+        // inputs are fetched kBatchLoads at a time (independent loads, one round trip per batch) before their block scans:
+        // enough to hide the latency when a single workgroup walks a short array, without the register cost of a whole tile
+        constexpr int kBatchLoads = 4;
+#pragma unroll
+        for (int k0 = 0; k0 < kItems; k0 += kBatchLoads) {
+            T v[kBatchLoads];
+#pragma unroll
+            for (int k = 0; k < kBatchLoads; k++) {
+                uint64_t i = base + (uint64_t)(k0 + k) * kThreads + threadIdx.x;
+                v[k] = i < n ? in(i) : T(0);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatchLoads; k++) {
+                uint64_t i = base + (uint64_t)(k0 + k) * kThreads + threadIdx.x;
+                T total;
+                T ex = block_exclusive_sum(v[k], lds, total);
+                if (i < n) out(i, carry + ex);
+                carry += total;
+            }
         }
     }
 }

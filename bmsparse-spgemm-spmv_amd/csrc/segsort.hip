@@ -134,6 +134,7 @@ struct SegClassify {
     const int *segs;
     uint32_t nseg;
     uint64_t n;
+    uint32_t wave_max;  // longest segment the one-wave kernel takes
     __device__ uint32_t len(uint64_t s) const
     {
         const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
@@ -145,7 +146,7 @@ struct SegClassify {
         if (s >= nseg) return 0;
         const uint32_t l = len(s);
         if (l <= 1) return 0;
-        return l <= kWaveSegMax ? 1ull : (l <= kBlockSegMax ? 1ull << 21 : 1ull << 42);
+        return l <= wave_max ? 1ull : (l <= kBlockSegMax ? 1ull << 21 : 1ull << 42);
     }
 };
 struct SegLists {
@@ -159,7 +160,7 @@ struct SegLists {
         const uint32_t l = c.len(s);
         if (l == 1) perm[c.segs[s]] = (uint32_t)c.segs[s];
         if (l <= 1) return;
-        if (l <= kWaveSegMax) wave_list[ex & 0x1fffffu] = (uint32_t)s;
+        if (l <= c.wave_max) wave_list[ex & 0x1fffffu] = (uint32_t)s;
         else if (l <= kBlockSegMax) block_list[(ex >> 21) & 0x1fffffu] = (uint32_t)s;
     }
 };
@@ -255,7 +256,7 @@ struct GatherVals {
 bool segsort_lds_perm(uint64_t *keys, uint32_t *perm, uint64_t n, const int *segs, uint32_t nseg, hipStream_t st)
 {
     if (nseg >= (1u << 21)) return false;  // packed 21-bit class counters
-    SegClassify cls{segs, nseg, n};
+    SegClassify cls{segs, nseg, n, kWaveSegMax};
     DevBuf<uint32_t> wave_list(nseg), block_list(nseg);
     DevBuf<uint64_t> tot(1);
     device_exclusive_scan<uint64_t>(cls, SegLists{cls, wave_list.p, block_list.p, tot.p, perm}, (uint64_t)nseg + 1, st);
@@ -340,6 +341,98 @@ void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const
     else fail(BMSP_ERR_INVALID, "val_bytes must be 4, 8 or 16");
 }
 
+// ------------------------------------------------------------------------------------------------
+// SpGEMM task lists: inside a block-row segment only the column part of the packed key varies, and a position inside
+// the segment needs <= 12 bits, so (column << idx_bits) | position is ONE machine word -- 32 bits whenever
+// jbits + idx_bits <= 32 -- and the bitonic network is a plain compare-exchange on LDS words (half / a quarter of the
+// LDS traffic of the generic (u64 key, u16 position) network above).  Segments up to 1024 tasks stay inside one wave
+// (no s_barrier between the network's steps); longer ones take a 512-thread workgroup.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kTaskWaveMax = 1024, kTaskWaveIdxBits = 10, kTaskBlockIdxBits = 12;
+
+template <typename W, int THREADS, bool BLOCK_SYNC>
+__device__ __forceinline__ void bitonic_words(W *a, uint32_t P, uint32_t tid)
+{
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t p = tid; p < P / 2; p += THREADS) {
+                const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const uint32_t q = i | j;
+                const W x = a[i], y = a[q];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { a[i] = y; a[q] = x; }
+            }
+            if (BLOCK_SYNC) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <typename W, int THREADS, bool BLOCK_SYNC, uint32_t IDX_BITS>
+__device__ __forceinline__ void sort_task_segment(W *a, uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, uint64_t lo, uint32_t len, uint32_t p_min,
+                                                  uint64_t col_mask, uint32_t tid)
+{
+    uint32_t P = p_min;
+    while (P < len) P <<= 1;
+    for (uint32_t e = tid; e < P; e += THREADS) a[e] = e < len ? (W)(((keys[lo + e] & col_mask) << IDX_BITS) | e) : (W)~(W)0;
+    const uint64_t row_part = keys[lo] & ~col_mask;  // read before any key of the segment is overwritten (barrier below)
+    if (BLOCK_SYNC) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();
+    bitonic_words<W, THREADS, BLOCK_SYNC>(a, P, tid);
+    for (uint32_t e = tid; e < len; e += THREADS) {
+        const W c = a[e];
+        keys[lo + e] = row_part | (uint64_t)(c >> IDX_BITS);
+        perm[lo + e] = (uint32_t)(lo + (uint32_t)(c & (W)((1u << IDX_BITS) - 1u)));
+    }
+}
+
+template <typename W>
+__global__ __launch_bounds__(kThreads) void segsort_tasks_wave_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, const int *__restrict__ segs,
+                                                                      uint32_t nseg, uint64_t n, const uint32_t *__restrict__ list, uint32_t count,
+                                                                      uint64_t col_mask)
+{
+    __shared__ W s_a[4][kTaskWaveMax];
+    const int w = wave_id();
+    const uint32_t li = blockIdx.x * 4 + w;
+    if (li >= count) return;
+    const uint32_t s = list[li];
+    const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
+    sort_task_segment<W, 64, false, kTaskWaveIdxBits>(s_a[w], keys, perm, lo, (uint32_t)(hi - lo), 2u, col_mask, (uint32_t)lane_id());
+}
+
+template <typename W>
+__global__ __launch_bounds__(512) void segsort_tasks_block_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, const int *__restrict__ segs,
+                                                                  uint32_t nseg, uint64_t n, const uint32_t *__restrict__ list, uint64_t col_mask)
+{
+    __shared__ W s_a[kBlockSegMax];
+    const uint32_t s = list[blockIdx.x];
+    const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
+    sort_task_segment<W, 512, true, kTaskBlockIdxBits>(s_a, keys, perm, lo, (uint32_t)(hi - lo), 1024u, col_mask, threadIdx.x);
+}
+
+template <typename W>
+bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *segs, uint32_t nseg, int jbits, hipStream_t st)
+{
+    if (nseg >= (1u << 21)) return false;
+    SegClassify cls{segs, nseg, n, kTaskWaveMax};
+    DevBuf<uint32_t> wave_list(nseg), block_list(nseg);
+    DevBuf<uint64_t> tot(1);
+    device_exclusive_scan<uint64_t>(cls, SegLists{cls, wave_list.p, block_list.p, tot.p, perm}, (uint64_t)nseg + 1, st);
+    const uint64_t t = read_back(tot.p, st);
+    const uint32_t n_wave = (uint32_t)(t & 0x1fffffu), n_block = (uint32_t)((t >> 21) & 0x1fffffu), n_long = (uint32_t)(t >> 42);
+    if (n_long) return false;
+    const uint64_t col_mask = (1ull << jbits) - 1ull;
+    if (n_wave) {
+        hipLaunchKernelGGL((segsort_tasks_wave_kernel<W>), dim3((n_wave + 3) / 4), dim3(kThreads), 0, st, keys, perm, segs, nseg, n, wave_list.p, n_wave, col_mask);
+        BMSP_CHECK_LAUNCH();
+    }
+    if (n_block) {
+        hipLaunchKernelGGL((segsort_tasks_block_kernel<W>), dim3(n_block), dim3(512), 0, st, keys, perm, segs, nseg, n, block_list.p, col_mask);
+        BMSP_CHECK_LAUNCH();
+    }
+    return true;
+}
+
 bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st)
 {
     if (n >= (1ull << 31)) return false;
@@ -350,7 +443,10 @@ bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals,
     device_exclusive_scan<uint32_t>(RunHead{keys.cur, n, jbits}, EmitRunStarts{keys.cur, n, jbits, segs.p, cnt.p}, n + 1, st);
     const uint32_t nseg = read_back(cnt.p, st);
     DevBuf<uint32_t> perm(n);
-    if (!segsort_lds_perm(keys.cur, perm.p, n, segs.p, nseg, st)) return false;  // hub rows: caller takes the global sort
+    const bool narrow = jbits + (int)kTaskBlockIdxBits <= 32;
+    const bool ok = narrow ? segsort_tasks_lds<uint32_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st)
+                           : segsort_tasks_lds<uint64_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st);
+    if (!ok) return false;  // hub rows: caller takes the global sort
     device_for_each(GatherVals<uint64_t>{vals.cur, perm.p, vals.alt}, n, st);
     vals.flip();
     return true;

@@ -280,7 +280,7 @@ def test_spgemm_fixtures_square(oracle, bmsp, path, dtype, tc):
         check_spgemm(oracle, bmsp, t, t, dtype, mode, tc, exact_expected=True)
 
 
-@pytest.mark.parametrize("case", ["rect", "banded", "rmat", "empty_rows", "filtered", "single_block"])
+@pytest.mark.parametrize("case", ["rect", "banded", "rmat", "empty_rows", "filtered", "single_block", "wide", "long_segments"])
 @pytest.mark.parametrize("dtype,tc", [(0, 5), (1, 5), (1, 4), (2, 5)])
 def test_spgemm_synthetic(oracle, bmsp, case, dtype, tc):
     from pybmsp import gen
@@ -294,6 +294,17 @@ def test_spgemm_synthetic(oracle, bmsp, case, dtype, tc):
     elif case == "empty_rows":
         A = gen.random_coo(500, 500, 400, seed=3, lo=0, hi=1)   # B has many empty block-rows; fan-out 0 tasks
         B = gen.random_coo(500, 500, 150, seed=4, lo=0, hi=1)
+    elif case == "wide":
+        # 2^24 columns: 21 column bits + 12 position bits do not fit a 32-bit sort word -> 64-bit words in the segmented sort
+        A = gen.random_coo(300, 200, 3000, seed=5, lo=0, hi=1)
+        B = gen.random_coo(200, 1 << 24, 6000, seed=6, lo=0, hi=1)
+    elif case == "long_segments":
+        # block-rows of A with ~300 .. ~3000 tasks: both LDS sort kernels (one wave <= 1024 tasks, workgroup <= 4096)
+        _, _, r1, c1, v1 = gen.random_coo(8, 400, 1500, seed=8, lo=0, hi=1)    # one heavy block-row
+        _, _, r2, c2, v2 = gen.random_coo(64, 400, 1000, seed=9, lo=0, hi=1)
+        rc, first = np.unique(np.concatenate([r1, r2]) * 400 + np.concatenate([c1, c2]), return_index=True)
+        A = (64, 400, rc // 400, rc % 400, np.concatenate([v1, v2])[first])
+        B = gen.random_coo(400, 3000, 12000, seed=10, lo=0, hi=1)
     elif case == "filtered":
         # A uses only even k, B only odd k inside every tile: every candidate pair dies in the bitmap filter
         n = 256
@@ -303,7 +314,7 @@ def test_spgemm_synthetic(oracle, bmsp, case, dtype, tc):
     else:
         A = (8, 8, np.array([0, 3]), np.array([1, 1]), np.array([2.0, 3.0]))
         B = (8, 8, np.array([1, 1]), np.array([0, 7]), np.array([5.0, 7.0]))
-    for mode in (2, 1):
+    for mode in (2, 1, 0):
         st = check_spgemm(oracle, bmsp, A, B, dtype, mode, tc)
     if case == "filtered":
         assert st["surviving_tasks"] == 0 and st["c_blocks"] == 0 and st["bmp_reduction"] == st["task_list_size"] > 0
