@@ -146,40 +146,47 @@ void device_exclusive_scan(In in, Out out, uint64_t n, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------
-// stable LSD radix sort of (uint64 key, payload) pairs, 8 bits per pass, n < 2^32
+// stable LSD radix sort of (uint64 key, payload) pairs, n < 2^32.  The digit width is chosen per sort (<= 9 bits): the
+// bits in use are split evenly over the fewest passes, e.g. 26 bits = 9 + 9 + 8 (three passes), 28 bits = 4 x 7.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRadixBits = 8;
-constexpr int kRadixBins = 1 << kRadixBits;
+constexpr int kRadixMaxBits = 9;
+constexpr int kRadixMaxBins = 1 << kRadixMaxBits;  // two bins per thread
 
-static __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint32_t n, int shift,
+static __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint32_t n, int shift, int bits,
                                                               uint32_t *__restrict__ hist, uint32_t num_tiles)
 {
-    __shared__ uint32_t h[kRadixBins];
+    __shared__ uint32_t h[kRadixMaxBins];
+    const uint32_t bins = 1u << bits, mask = bins - 1u;
     h[threadIdx.x] = 0;
+    h[threadIdx.x + kThreads] = 0;
     __syncthreads();
     uint64_t base = (uint64_t)blockIdx.x * kTile;
 #pragma unroll 4
     for (int k = 0; k < kItems; k++) {
         uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
-        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (kRadixBins - 1)], 1u);
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[(uint64_t)threadIdx.x * num_tiles + blockIdx.x] = h[threadIdx.x];
+    for (uint32_t d = threadIdx.x; d < bins; d += kThreads) hist[(uint64_t)d * num_tiles + blockIdx.x] = h[d];
 }
 
 // Each wave owns a contiguous 1024-key slice of the tile and ranks it 64 keys at a time: lanes holding the
-// same digit find each other with 8 ballots, the lowest of them bumps the wave's LDS counter for that digit,
-// and every peer takes (old count + its position among the peers).  Slices, rounds and lanes are all visited
+// same digit find each other with one ballot per digit bit, the lowest of them bumps the wave's LDS counter for that
+// digit, and every peer takes (old count + its position among the peers).  Slices, rounds and lanes are all visited
 // in index order, so equal digits keep their input order (stable).
 template <typename P>
 __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t *__restrict__ kin, const P *__restrict__ pin,
                                                                  uint64_t *__restrict__ kout, P *__restrict__ pout, uint32_t n,
-                                                                 int shift, const uint32_t *__restrict__ hist_scanned,
+                                                                 int shift, int bits, const uint32_t *__restrict__ hist_scanned,
                                                                  uint32_t num_tiles)
 {
-    __shared__ uint32_t cnt[4][kRadixBins];
-    __shared__ uint32_t dst_base[4][kRadixBins];
-    for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
+    __shared__ uint32_t cnt[4][kRadixMaxBins];
+    __shared__ uint32_t dst_base[4][kRadixMaxBins];
+    const uint32_t bins = 1u << bits, mask = bins - 1u;
+    for (int w = 0; w < 4; w++) {
+        cnt[w][threadIdx.x] = 0;
+        cnt[w][threadIdx.x + kThreads] = 0;
+    }
     __syncthreads();
     const int w = wave_id(), lane = lane_id();
     const uint64_t slice = (uint64_t)blockIdx.x * kTile + (uint64_t)w * (kTile / 4);
@@ -191,13 +198,15 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
         uint64_t i = slice + (uint64_t)r * kWave + lane;
         bool valid = i < n;
         key[r] = valid ? kin[i] : ~0ull;
-        uint32_t d = (uint32_t)(key[r] >> shift) & (kRadixBins - 1);
+        uint32_t d = (uint32_t)(key[r] >> shift) & mask;
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < kRadixBits; b++) {
-            bool bit = (d >> b) & 1u;
-            uint64_t m = __ballot(valid && bit);
-            peers &= bit ? m : ~m;
+        for (int b = 0; b < kRadixMaxBits; b++) {
+            if (b < bits) {  // wave-uniform
+                bool bit = (d >> b) & 1u;
+                uint64_t m = __ballot(valid && bit);
+                peers &= bit ? m : ~m;
+            }
         }
         uint32_t old = 0;
         int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
@@ -206,8 +215,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
         rnk[r] = old + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
-    {
-        uint32_t d = threadIdx.x;
+    for (uint32_t d = threadIdx.x; d < bins; d += kThreads) {
         uint32_t g = hist_scanned[(uint64_t)d * num_tiles + blockIdx.x];
 #pragma unroll
         for (int ww = 0; ww < 4; ww++) {
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
     for (int r = 0; r < kItems; r++) {
         uint64_t i = slice + (uint64_t)r * kWave + lane;
         if (i < n) {
-            uint32_t d = (uint32_t)(key[r] >> shift) & (kRadixBins - 1);
+            uint32_t d = (uint32_t)(key[r] >> shift) & mask;
             uint32_t dst = dst_base[w][d] + rnk[r];
             kout[dst] = key[r];
             pout[dst] = pin[i];
@@ -251,13 +259,17 @@ void device_radix_sort_pairs(PingPong<uint64_t> &keys, PingPong<P> &vals, uint64
                                   (unsigned long long)n64);
     uint32_t n = (uint32_t)n64;
     uint32_t tiles = (uint32_t)((n64 + kTile - 1) / kTile);
-    DevBuf<uint32_t> hist((size_t)kRadixBins * tiles);
-    for (int shift = begin_bit; shift < end_bit; shift += kRadixBits) {
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(kThreads), 0, st, keys.cur, n, shift, hist.p, tiles);
+    const int total_bits = end_bit - begin_bit;
+    const int passes = (total_bits + kRadixMaxBits - 1) / kRadixMaxBits;
+    const int width = (total_bits + passes - 1) / passes;
+    DevBuf<uint32_t> hist((size_t)(1u << width) * tiles);
+    for (int shift = begin_bit; shift < end_bit; shift += width) {
+        const int bits = std::min(width, end_bit - shift);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(kThreads), 0, st, keys.cur, n, shift, bits, hist.p, tiles);
         BMSP_CHECK_LAUNCH();
-        device_exclusive_scan<uint32_t>(PtrIn<uint32_t>{hist.p}, PtrOut<uint32_t>{hist.p}, (uint64_t)kRadixBins * tiles, st);
+        device_exclusive_scan<uint32_t>(PtrIn<uint32_t>{hist.p}, PtrOut<uint32_t>{hist.p}, (uint64_t)(1u << bits) * tiles, st);
         hipLaunchKernelGGL((radix_scatter_kernel<P>), dim3(tiles), dim3(kThreads), 0, st, keys.cur, vals.cur, keys.alt,
-                           vals.alt, n, shift, hist.p, tiles);
+                           vals.alt, n, shift, bits, hist.p, tiles);
         BMSP_CHECK_LAUNCH();
         keys.flip();
         vals.flip();
