@@ -167,36 +167,68 @@ struct EmitCBlocks {
     int jbits;
     uint64_t *c_keys;
     uint32_t *task_begin;
+    uint32_t *c_of_wave;  // C block of task 64 w, for the task-parallel bitmap pass (T_9)
+    uint32_t *c_size;
     __device__ void operator()(uint64_t t, uint32_t ex) const
     {
         if (t == n) {
             task_begin[ex] = (uint32_t)n;
+            *c_size = ex;
             return;
         }
-        if (t == 0 || sk[t] != sk[t - 1]) {
+        const bool head = t == 0 || sk[t] != sk[t - 1];
+        if (head) {
             uint64_t k = sk[t];
             c_keys[ex] = key_make((uint32_t)(k >> jbits), (uint32_t)(k & ((1ull << jbits) - 1ull)));
             task_begin[ex] = (uint32_t)t;
         }
+        if ((t & 63u) == 0) c_of_wave[t >> 6] = head ? ex : ex - 1u;
     }
 };
 
 // ---- T_9: bitmap of every C block = OR of the boolean products of its tasks ---------------------------------
-struct CBitmaps {
-    const uint64_t *tasks;
-    const uint32_t *task_begin;
-    const uint64_t *a_bmps, *b_bmps;
-    uint64_t *c_bmps;
-    __device__ void operator()(uint64_t c) const
-    {
-        uint64_t acc = 0;
-        for (uint32_t t = task_begin[c]; t < task_begin[c + 1]; t++) {
-            uint64_t tk = tasks[t];
-            acc |= tile_product_bmp(a_bmps[tk >> 32], b_bmps[(uint32_t)tk]);  // bmp_calculator (:787-810)
-        }
-        c_bmps[c] = acc;
+// Task-parallel: a wave takes 64 consecutive tasks of the sorted list (coalesced reads, two bitmap gathers per lane),
+// ORs the products of equal-key runs with a segmented scan across lanes, and the last lane of every run writes the C
+// bitmap -- with a plain store when the run lies inside the wave, with an atomic OR when it crosses a wave boundary
+// (hub C blocks with thousands of tasks become one atomic per wave instead of one serial loop).  c_bmps starts zeroed.
+__global__ __launch_bounds__(kThreads) void c_bitmaps_kernel(const uint64_t *__restrict__ sk, const uint64_t *__restrict__ tasks, uint32_t n,
+                                                             const uint32_t *__restrict__ c_of_wave, const uint64_t *__restrict__ a_bmps,
+                                                             const uint64_t *__restrict__ b_bmps, unsigned long long *__restrict__ c_bmps)
+{
+    const int lane = lane_id();
+    const uint32_t wv = blockIdx.x * 4 + wave_id();
+    const uint32_t t = wv * 64u + (uint32_t)lane;
+    if (wv * 64u >= n) return;
+    const bool valid = t < n;
+    const uint64_t key = valid ? sk[t] : ~0ull;
+    uint64_t p = 0;
+    if (valid) {
+        const uint64_t tk = tasks[t];
+        p = tile_product_bmp(a_bmps[tk >> 32], b_bmps[(uint32_t)tk]);  // bmp_calculator (:787-810)
     }
-};
+    // run boundaries from the neighbours' keys (the wave's edges look across to the adjacent tasks)
+    uint64_t prev = __shfl_up(key, 1, kWave), next = __shfl_down(key, 1, kWave);
+    if (lane == 0) prev = t > 0 ? sk[t - 1] : ~key;
+    if (lane == 63) next = (valid && t + 1 < n) ? sk[t + 1] : ~key;
+    const bool head = valid && key != prev, tail = valid && key != next;
+    const uint64_t head_mask = __ballot(head);
+    const uint64_t le = lanemask_lt() | (1ull << lane);
+    // first lane of this lane's run inside the wave (lane 0 when the run began in an earlier wave)
+    const int start = 63 - __clzll((long long)((head_mask | 1ull) & le));
+    // segmented inclusive OR: lane l collects lanes [start, l]
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t q = __shfl_up(p, d, kWave);
+        if (lane - d >= start) p |= q;
+    }
+    if (valid && (tail || lane == 63)) {
+        const uint32_t c = c_of_wave[wv] + (uint32_t)__popcll(head_mask & le & ~1ull);
+        // the whole run lies inside this wave: nobody else writes this C block
+        if (tail && ((head_mask >> start) & 1ull)) c_bmps[c] = p;
+        else atomicOr(&c_bmps[c], (unsigned long long)p);
+    }
+}
+
 struct PopcIn {
     const uint64_t *bmps;
     uint64_t n;
@@ -859,11 +891,17 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     }
     tm.mark(5);
 
-    // T_6: C's block keys and the task range of every C block
+    // T_6: C's block keys and the task range of every C block.  One scan: the keys and task ranges are emitted into
+    // task-sized scratch and C's own key array is cut to size once the block count is known (a counting scan first, as the
+    // reference's reduce_by_key does internally, would read the sorted keys twice more).
     DevBuf<uint32_t> csize_d(1);
     uint32_t c_size = 0;
+    DevBuf<uint64_t> c_keys_scratch((size_t)n_tasks);
+    DevBuf<uint32_t> task_begin((size_t)n_tasks + 1);
+    DevBuf<uint32_t> c_of_wave((size_t)(n_tasks / 64 + 1));
     if (n_tasks) {
-        device_exclusive_scan<uint32_t>(KeyHead{kk.cur, n_tasks}, TotalOut32{n_tasks, csize_d.p}, n_tasks + 1, st);
+        device_exclusive_scan<uint32_t>(KeyHead{kk.cur, n_tasks}, EmitCBlocks{kk.cur, n_tasks, jbits, c_keys_scratch.p, task_begin.p, c_of_wave.p, csize_d.p},
+                                        n_tasks + 1, st);
         c_size = read_back(csize_d.p, st);
     }
     std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> C(new bmsp_matrix_s(), free_matrix);
@@ -874,15 +912,16 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     C->keys = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
     C->bmps = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
     C->offsets = (uint64_t *)pool_alloc(8 * ((size_t)c_size + 1));
-    DevBuf<uint32_t> task_begin((size_t)c_size + 1);
-    if (n_tasks)
-        device_exclusive_scan<uint32_t>(KeyHead{kk.cur, n_tasks}, EmitCBlocks{kk.cur, n_tasks, jbits, C->keys, task_begin.p}, n_tasks + 1, st);
+    if (c_size) BMSP_HIP(hipMemcpyAsync(C->keys, c_keys_scratch.p, 8 * (size_t)c_size, hipMemcpyDeviceToDevice, st));
     tm.mark(6);
 
     // T_9: C bitmaps, value offsets, nnz
     uint64_t c_nnz = 0;
     if (c_size) {
-        device_for_each(CBitmaps{vv.cur, task_begin.p, A->bmps, B->bmps, C->bmps}, c_size, st);
+        BMSP_HIP(hipMemsetAsync(C->bmps, 0, 8 * (size_t)c_size, st));
+        hipLaunchKernelGGL(c_bitmaps_kernel, dim3((uint32_t)((n_tasks + 255) / 256)), dim3(kThreads), 0, st, kk.cur, vv.cur, (uint32_t)n_tasks, c_of_wave.p,
+                           A->bmps, B->bmps, (unsigned long long *)C->bmps);
+        BMSP_CHECK_LAUNCH();
         device_exclusive_scan<uint64_t>(PopcIn{C->bmps, c_size}, PtrOut<uint64_t>{C->offsets}, (uint64_t)c_size + 1, st);
         c_nnz = read_back(C->offsets + c_size, st);
     } else {
