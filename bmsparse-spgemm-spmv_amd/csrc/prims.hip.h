@@ -78,6 +78,18 @@ __global__ __launch_bounds__(kThreads) void scan_tile_sums_kernel(In in, uint64_
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
+// Out functors may take the element's own input value as a third argument (saves re-deriving it from memory)
+template <typename Out, typename T>
+__device__ __forceinline__ auto scan_emit(const Out &o, uint64_t i, T ex, T v, int) -> decltype(o(i, ex, v), void())
+{
+    o(i, ex, v);
+}
+template <typename Out, typename T>
+__device__ __forceinline__ void scan_emit(const Out &o, uint64_t i, T ex, T, long)
+{
+    o(i, ex);
+}
+
 template <typename T, typename In, typename Out>
 __global__ __launch_bounds__(kThreads) void scan_tile_down_kernel(In in, Out out, uint64_t n, const T *tile_excl,
                                                                   uint64_t tiles_per_block)
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void scan_tile_down_kernel(In in, Out out
                 uint64_t i = base + (uint64_t)(k0 + k) * kThreads + threadIdx.x;
                 T total;
                 T ex = block_exclusive_sum(v[k], lds, total);
-                if (i < n) out(i, carry + ex);
+                if (i < n) scan_emit<Out, T>(out, i, carry + ex, v[k], 0);
                 carry += total;
             }
         }
@@ -301,6 +313,37 @@ void device_for_each(F f, uint64_t n, hipStream_t st)
     hipLaunchKernelGGL((for_each_kernel<F>), grid_for(n), dim3(kThreads), 0, st, f, n);
     BMSP_CHECK_LAUNCH();
 }
+
+// A scalar a kernel hands to the host: the slot is pinned host memory the device writes straight into, so fetching it is a
+// stream synchronise and a host load -- no copy kernel, no staging (read_back below costs a blit launch per scalar).
+void *host_slot_acquire();
+void host_slot_release(void *p);
+template <typename T>
+struct HostScalar {
+    T *p;
+    HostScalar() : p(static_cast<T *>(host_slot_acquire())) { *p = T(0); }
+    HostScalar(const HostScalar &) = delete;
+    HostScalar &operator=(const HostScalar &) = delete;
+    ~HostScalar() { host_slot_release(p); }
+    T *dev() const { return p; }  // device-accessible address
+    T wait(hipStream_t st) const
+    {
+        BMSP_HIP(hipStreamSynchronize(st));
+        return *(volatile T *)p;
+    }
+};
+// PtrOut that also publishes the element at index `last` (the scan total) to a host scalar
+template <typename T>
+struct PtrOutTotal {
+    T *p;
+    uint64_t last;
+    T *total;
+    __device__ void operator()(uint64_t i, T v) const
+    {
+        p[i] = v;
+        if (i == last) *total = v;
+    }
+};
 
 template <typename T>
 T read_back(const T *dptr, hipStream_t st)

@@ -86,6 +86,46 @@ void pool_free(void *p)
     P.free_blocks[it->second].push_back(p);
 }
 
+// ---- pinned host scalars (prims.hip.h: HostScalar) ----------------------------------------------------------
+namespace {
+struct SlotPool {
+    std::mutex mu;
+    std::vector<void *> free_slots;
+};
+SlotPool &slots()
+{
+    static SlotPool *p = new SlotPool();
+    return *p;
+}
+}  // namespace
+
+void *host_slot_acquire()
+{
+    SlotPool &S = slots();
+    {
+        std::lock_guard<std::mutex> lk(S.mu);
+        if (!S.free_slots.empty()) {
+            void *p = S.free_slots.back();
+            S.free_slots.pop_back();
+            return p;
+        }
+    }
+    // one page of 64-byte slots per refill; never returned to the driver (a handful of pages per process)
+    char *page = nullptr;
+    BMSP_HIP(hipHostMalloc((void **)&page, 4096, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lk(S.mu);
+    for (int i = 1; i < 64; i++) S.free_slots.push_back(page + 64 * i);
+    return page;
+}
+
+void host_slot_release(void *p)
+{
+    if (!p) return;
+    SlotPool &S = slots();
+    std::lock_guard<std::mutex> lk(S.mu);
+    S.free_slots.push_back(p);
+}
+
 bool pool_owns(void *p)
 {
     Pool &P = pool();

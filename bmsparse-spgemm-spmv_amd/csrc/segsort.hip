@@ -154,14 +154,15 @@ struct SegLists {
     uint32_t *wave_list, *block_list;
     uint64_t *totals;
     uint32_t *perm;  // identity is written for unit segments
-    __device__ void operator()(uint64_t s, uint64_t ex) const
+    __device__ void operator()(uint64_t s, uint64_t ex, uint64_t cls) const
     {
         if (s == c.nseg) { *totals = ex; return; }
-        const uint32_t l = c.len(s);
-        if (l == 1) perm[c.segs[s]] = (uint32_t)c.segs[s];
-        if (l <= 1) return;
-        if (l <= c.wave_max) wave_list[ex & 0x1fffffu] = (uint32_t)s;
-        else if (l <= kBlockSegMax) block_list[(ex >> 21) & 0x1fffffu] = (uint32_t)s;
+        if (cls == 0) {  // length 0 or 1
+            if (c.len(s) == 1) perm[c.segs[s]] = (uint32_t)c.segs[s];
+            return;
+        }
+        if (cls == 1ull) wave_list[ex & 0x1fffffu] = (uint32_t)s;
+        else if (cls == (1ull << 21)) block_list[(ex >> 21) & 0x1fffffu] = (uint32_t)s;
     }
 };
 
@@ -305,10 +306,10 @@ struct EmitRunStarts {
     int shift;
     int *segs;
     uint32_t *count;
-    __device__ void operator()(uint64_t i, uint32_t ex) const
+    __device__ void operator()(uint64_t i, uint32_t ex, uint32_t is_head) const
     {
         if (i == n) { *count = ex; return; }
-        if (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) segs[ex] = (int)i;
+        if (is_head) segs[ex] = (int)i;  // RunHead's value for this element
     }
 };
 struct MaskLow {
@@ -416,9 +417,9 @@ bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *se
     if (nseg >= (1u << 21)) return false;
     SegClassify cls{segs, nseg, n, kTaskWaveMax};
     DevBuf<uint32_t> wave_list(nseg), block_list(nseg);
-    DevBuf<uint64_t> tot(1);
-    device_exclusive_scan<uint64_t>(cls, SegLists{cls, wave_list.p, block_list.p, tot.p, perm}, (uint64_t)nseg + 1, st);
-    const uint64_t t = read_back(tot.p, st);
+    HostScalar<uint64_t> tot;
+    device_exclusive_scan<uint64_t>(cls, SegLists{cls, wave_list.p, block_list.p, tot.dev(), perm}, (uint64_t)nseg + 1, st);
+    const uint64_t t = tot.wait(st);
     const uint32_t n_wave = (uint32_t)(t & 0x1fffffu), n_block = (uint32_t)((t >> 21) & 0x1fffffu), n_long = (uint32_t)(t >> 42);
     if (n_long) return false;
     const uint64_t col_mask = (1ull << jbits) - 1ull;
@@ -439,9 +440,9 @@ bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals,
     // segments = runs of equal block-row (reference: :982-1004).  Inside a run the row part of the packed key is
     // constant, so comparing whole keys orders by column: no masking pass is needed.
     DevBuf<int> segs(n);
-    DevBuf<uint32_t> cnt(1);
-    device_exclusive_scan<uint32_t>(RunHead{keys.cur, n, jbits}, EmitRunStarts{keys.cur, n, jbits, segs.p, cnt.p}, n + 1, st);
-    const uint32_t nseg = read_back(cnt.p, st);
+    HostScalar<uint32_t> cnt;
+    device_exclusive_scan<uint32_t>(RunHead{keys.cur, n, jbits}, EmitRunStarts{keys.cur, n, jbits, segs.p, cnt.dev()}, n + 1, st);
+    const uint32_t nseg = cnt.wait(st);
     DevBuf<uint32_t> perm(n);
     const bool narrow = jbits + (int)kTaskBlockIdxBits <= 32;
     const bool ok = narrow ? segsort_tasks_lds<uint32_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st)

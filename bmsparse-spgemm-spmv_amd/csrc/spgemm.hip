@@ -169,14 +169,14 @@ struct EmitCBlocks {
     uint32_t *task_begin;
     uint32_t *c_of_wave;  // C block of task 64 w, for the task-parallel bitmap pass (T_9)
     uint32_t *c_size;
-    __device__ void operator()(uint64_t t, uint32_t ex) const
+    __device__ void operator()(uint64_t t, uint32_t ex, uint32_t is_head) const
     {
         if (t == n) {
             task_begin[ex] = (uint32_t)n;
             *c_size = ex;
             return;
         }
-        const bool head = t == 0 || sk[t] != sk[t - 1];
+        const bool head = is_head != 0;  // KeyHead's value for this task
         if (head) {
             uint64_t k = sk[t];
             c_keys[ex] = key_make((uint32_t)(k >> jbits), (uint32_t)(k & ((1ull << jbits) - 1ull)));
@@ -838,9 +838,10 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     // T_2 + T_3 (first half): fan-out per A block and its exclusive scan
     const uint64_t n_a = (uint64_t)A->block_num;
     DevBuf<uint64_t> first_pos(n_a + 1);
-    device_exclusive_scan<uint64_t>(FanOut{A->keys, B->rowptr, n_a, (uint32_t)B->num_block_rows()}, PtrOut<uint64_t>{first_pos.p},
+    HostScalar<uint64_t> total_h;
+    device_exclusive_scan<uint64_t>(FanOut{A->keys, B->rowptr, n_a, (uint32_t)B->num_block_rows()}, PtrOutTotal<uint64_t>{first_pos.p, n_a, total_h.dev()},
                                     n_a + 1, st);
-    const uint64_t total = read_back(first_pos.p + n_a, st);
+    const uint64_t total = total_h.wait(st);
     tm.mark(2);
     S->task_list_size = (int64_t)total;
     if (total >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "%llu candidate block pairs exceed the 32-bit task range; shard by row panel", (unsigned long long)total);
@@ -858,8 +859,9 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
                            (uint64_t *)nullptr, (uint64_t *)nullptr);
         BMSP_CHECK_LAUNCH();
         DevBuf<uint32_t> tile_base((size_t)tiles + 1);
-        device_exclusive_scan<uint32_t>(CountIn{tile_counts.p, tiles}, PtrOut<uint32_t>{tile_base.p}, (uint64_t)tiles + 1, st);
-        n_tasks = read_back(tile_base.p + tiles, st);
+        HostScalar<uint32_t> n_tasks_h;
+        device_exclusive_scan<uint32_t>(CountIn{tile_counts.p, tiles}, PtrOutTotal<uint32_t>{tile_base.p, tiles, n_tasks_h.dev()}, (uint64_t)tiles + 1, st);
+        n_tasks = n_tasks_h.wait(st);
         tm.mark(3);
         k0.alloc(n_tasks); k1.alloc(n_tasks); v0.alloc(n_tasks); v1.alloc(n_tasks);
         hipLaunchKernelGGL((expand_filter_kernel<true>), dim3(tiles), dim3(kThreads), 0, st, ea, (uint32_t *)nullptr,
@@ -894,15 +896,15 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     // T_6: C's block keys and the task range of every C block.  One scan: the keys and task ranges are emitted into
     // task-sized scratch and C's own key array is cut to size once the block count is known (a counting scan first, as the
     // reference's reduce_by_key does internally, would read the sorted keys twice more).
-    DevBuf<uint32_t> csize_d(1);
+    HostScalar<uint32_t> csize_h;
     uint32_t c_size = 0;
     DevBuf<uint64_t> c_keys_scratch((size_t)n_tasks);
     DevBuf<uint32_t> task_begin((size_t)n_tasks + 1);
     DevBuf<uint32_t> c_of_wave((size_t)(n_tasks / 64 + 1));
     if (n_tasks) {
-        device_exclusive_scan<uint32_t>(KeyHead{kk.cur, n_tasks}, EmitCBlocks{kk.cur, n_tasks, jbits, c_keys_scratch.p, task_begin.p, c_of_wave.p, csize_d.p},
+        device_exclusive_scan<uint32_t>(KeyHead{kk.cur, n_tasks}, EmitCBlocks{kk.cur, n_tasks, jbits, c_keys_scratch.p, task_begin.p, c_of_wave.p, csize_h.dev()},
                                         n_tasks + 1, st);
-        c_size = read_back(csize_d.p, st);
+        c_size = csize_h.wait(st);
     }
     std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> C(new bmsp_matrix_s(), free_matrix);
     C->num_rows = A->num_rows; C->num_cols = B->num_cols;  // :1171-1172
@@ -922,8 +924,9 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         hipLaunchKernelGGL(c_bitmaps_kernel, dim3((uint32_t)((n_tasks + 255) / 256)), dim3(kThreads), 0, st, kk.cur, vv.cur, (uint32_t)n_tasks, c_of_wave.p,
                            A->bmps, B->bmps, (unsigned long long *)C->bmps);
         BMSP_CHECK_LAUNCH();
-        device_exclusive_scan<uint64_t>(PopcIn{C->bmps, c_size}, PtrOut<uint64_t>{C->offsets}, (uint64_t)c_size + 1, st);
-        c_nnz = read_back(C->offsets + c_size, st);
+        HostScalar<uint64_t> c_nnz_h;
+        device_exclusive_scan<uint64_t>(PopcIn{C->bmps, c_size}, PtrOutTotal<uint64_t>{C->offsets, c_size, c_nnz_h.dev()}, (uint64_t)c_size + 1, st);
+        c_nnz = c_nnz_h.wait(st);
     } else {
         BMSP_HIP(hipMemsetAsync(C->offsets, 0, 8, st));
     }
