@@ -6,16 +6,17 @@
 //
 // MI355X design (variant 0, the default): the block-vector sweep.
 //   * A per-matrix SWEEP PLAN (built once, cached like the block-row pointer) cuts the block array into wave-sized
-//     work items.  Short block-rows are grouped into items aligned to block-row boundaries (<= 64 block-rows inside
-//     one aligned 64-row window, < 256 tiles), so an item owns a contiguous slice of u outright.  A block-row with
-//     more than 128 tiles (hub rows of web / R-MAT graphs) is cut into 128-tile items of its own.
+//     work items.  Short block-rows are grouped into items aligned to block-row boundaries (<= 16 block-rows inside
+//     one aligned 16-row window, < 512 tiles), so an item owns a contiguous slice of u outright.  A block-row with
+//     more than 256 tiles (hub rows of web / R-MAT graphs) is cut into 256-tile items of its own.
 //   * One wave per item.  Lane l loads key / bitmap / offset of tiles l and l+64 of a 128-tile batch: three fully
 //     coalesced streams, no dependent pointer chase.  Work per lane is one tile whatever the row lengths are, so
 //     skewed graphs stay balanced.
-//       sparse tiles (<= 8 stored values): the lane peels the elements off the top of the bitmap and issues all their
-//         value / x gathers back to back (buffer loads against wave-uniform descriptors; an absent element points out
-//         of range and reads 0, so there is no branch and no 64-bit address arithmetic), then adds the products into
-//         the item's u tile in LDS (64 block-rows x 8 rows per wave).
+//       sparse tiles (<= 8 stored values): the lane peels the first two elements off the top of the bitmap and issues
+//         their value / x gathers back to back (buffer loads against wave-uniform descriptors; an absent element points
+//         out of range and reads 0, so there is no branch and no 64-bit address arithmetic), then adds the products into
+//         the item's u tile in LDS (16 block-rows x 8 rows per wave); tiles with more values wait in an LDS queue that
+//         is drained 64 tiles at a time, so every lane of a drain has work.
 //       dense tiles: queued in LDS and swept by the whole wave, lane p = tile position p (contiguous value loads),
 //         8-lane DPP row sums, one LDS add per tile row.
 //   * Short items store their u slice with coalesced stores (empty block-rows come out as zeros for free).
