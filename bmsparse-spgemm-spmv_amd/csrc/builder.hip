@@ -374,6 +374,7 @@ void free_matrix(bmsp_matrix_s *m)
     }
     pool_free(m->rowptr);
     pool_free(m->spmv_chunks);
+    pool_free(m->block_meta);
     delete m;
 }
 
@@ -385,6 +386,27 @@ void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st)
     m->rowptr = (uint32_t *)pool_alloc(sizeof(uint32_t) * (size_t)(nbr + 1));
     m->rowptr_rows = nbr;
     device_for_each(RowPtrSearch{m->keys, (uint32_t)m->block_num, m->rowptr}, (uint64_t)nbr + 1, st);
+}
+
+namespace {
+struct PackBlockMeta {
+    const uint64_t *bmps, *offsets;
+    uint32_t *meta;
+    __device__ void operator()(uint64_t b) const
+    {
+        const uint64_t bm = bmps[b];
+        uint32_t *r = meta + 4 * b;
+        r[0] = (uint32_t)bm; r[1] = (uint32_t)(bm >> 32); r[2] = (uint32_t)offsets[b]; r[3] = 0u;
+    }
+};
+}  // namespace
+
+void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st)
+{
+    if (m->block_meta) return;
+    if ((uint64_t)m->values_extent() >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "packed block records hold 32-bit value offsets");
+    m->block_meta = (uint32_t *)pool_alloc(16 * (size_t)(m->block_num ? m->block_num : 1));
+    if (m->block_num) device_for_each(PackBlockMeta{m->bmps, m->offsets, m->block_meta}, (uint64_t)m->block_num, st);
 }
 
 bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, const int *d_rows, const int *d_cols,

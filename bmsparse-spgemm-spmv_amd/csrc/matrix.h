@@ -25,6 +25,8 @@ struct bmsp_matrix_s {
     int64_t spmv_num_chunks = 0;
     int64_t spmv_plan_long = 0;
     size_t spmv_plan_off_cnt = 0, spmv_plan_off_carry = 0;
+    // (bitmap, value offset) of every block as one 16-byte record, for kernels that gather both (block-MAC): built lazily
+    uint32_t *block_meta = nullptr;  // block_num x {bmp lo, bmp hi, offset in elements, 0}
     // a row-panel view points into its parent
     int64_t view_block_begin = 0;
 
@@ -55,6 +57,7 @@ bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, co
                                      const double *d_vals, int transposed, bmsp_dtype dtype, hipStream_t st);
 
 void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st);
+void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st);
 void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st);
 void matrix_to_coo_device_split(bmsp_matrix_s *m, int *d_rows, int *d_cols, double *d_vals, hipStream_t st);
 void matrix_to_csr_device(bmsp_matrix_s *m, int *d_row_offsets, int *d_cols, double *d_vals, hipStream_t st);

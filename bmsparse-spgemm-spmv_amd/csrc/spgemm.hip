@@ -476,12 +476,22 @@ struct MacMeta {
     uint32_t aoff[64], boff[64];
 };
 
+// a_meta / b_meta: the matrices' packed block records {bitmap lo, bitmap hi, value offset, 0} (matrix.h: block_meta) -- one
+// 16-byte gather per operand block instead of a bitmap gather and an offset gather
 #define BMSP_MAC_ARGS                                                                                                              \
-    const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin, const uint64_t *__restrict__ a_bmps,                  \
-        const uint64_t *__restrict__ a_offs, const _Float16 *__restrict__ a_vals, const uint64_t *__restrict__ b_bmps,                 \
-        const uint64_t *__restrict__ b_offs, const _Float16 *__restrict__ b_vals, const uint64_t *__restrict__ c_bmps,                 \
-        const uint64_t *__restrict__ c_offs, float *__restrict__ c_vals, uint32_t c_size, uint32_t a_bytes, uint32_t b_bytes
-#define BMSP_MAC_PASS tasks, task_begin, a_bmps, a_offs, a_vals, b_bmps, b_offs, b_vals, c_bmps, c_offs, c_vals, c_size, a_bytes, b_bytes
+    const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin, const uint32_t *__restrict__ a_meta,                  \
+        uint32_t a_meta_bytes, const _Float16 *__restrict__ a_vals, const uint32_t *__restrict__ b_meta, uint32_t b_meta_bytes,        \
+        const _Float16 *__restrict__ b_vals, const uint64_t *__restrict__ c_bmps, const uint64_t *__restrict__ c_offs,                 \
+        float *__restrict__ c_vals, uint32_t c_size, uint32_t a_bytes, uint32_t b_bytes
+#define BMSP_MAC_PASS tasks, task_begin, a_meta, a_meta_bytes, a_vals, b_meta, b_meta_bytes, b_vals, c_bmps, c_offs, c_vals, c_size, a_bytes, b_bytes
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_block_meta(rsrc_t r, uint32_t block, uint64_t &bmp, uint32_t &off_elems)
+{
+    const u32x4_t m = __builtin_amdgcn_raw_buffer_load_b128(r, block << 4, 0, 0);
+    bmp = ((uint64_t)m[1] << 32) | m[0];
+    off_elems = m[2];
+}
 
 template <int kGroupC>
 __device__ __forceinline__ void block_mac_group_body(BMSP_MAC_ARGS)
@@ -500,6 +510,7 @@ __device__ __forceinline__ void block_mac_group_body(BMSP_MAC_ARGS)
     if (threadIdx.x < 16) s_sel[threadIdx.x] = nibble_selector(threadIdx.x);
     __syncthreads();
     const rsrc_t ra = make_rsrc(a_vals, a_bytes), rb = make_rsrc(b_vals, b_bytes);
+    const rsrc_t rma = make_rsrc(a_meta, a_meta_bytes), rmb = make_rsrc(b_meta, b_meta_bytes);
     const uint32_t groups = (c_size + kGroupC - 1) / kGroupC;
     const uint32_t g0 = blockIdx.x * 4 + w, stride = gridDim.x * 4;
     const uint32_t mine = g0 < groups ? (groups - g0 + stride - 1) / stride : 0u;
@@ -523,9 +534,9 @@ __device__ __forceinline__ void block_mac_group_body(BMSP_MAC_ARGS)
         {
             const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)tbv2, 0), te = (uint32_t)__builtin_amdgcn_readlane((int)tbv2, kGroupC);
             if (tb + lane < min(te, tb + 64u)) {
-                const uint32_t a = (uint32_t)(tk2 >> 32), b = (uint32_t)tk2;
-                m_abmp = a_bmps[a]; m_aoff = (uint32_t)a_offs[a] * 2u;
-                m_bbmp = b_bmps[b]; m_boff = (uint32_t)b_offs[b] * 2u;
+                load_block_meta(rma, (uint32_t)(tk2 >> 32), m_abmp, m_aoff);
+                load_block_meta(rmb, (uint32_t)tk2, m_bbmp, m_boff);
+                m_aoff *= 2u; m_boff *= 2u;
             }
             if (have2 && lane < kGroupC) {
                 const uint32_t cc = min((g0 + (k - 2) * stride) * kGroupC + (uint32_t)lane, c_size - 1);
@@ -549,9 +560,12 @@ __device__ __forceinline__ void block_mac_group_body(BMSP_MAC_ARGS)
                     __builtin_amdgcn_wave_barrier();
                     if (lo + lane < hi) {
                         const uint64_t tk = tasks[lo + lane];
-                        const uint32_t a = (uint32_t)(tk >> 32), b = (uint32_t)tk;
-                        M.abmp[lane] = a_bmps[a]; M.aoff[lane] = (uint32_t)a_offs[a] * 2u;
-                        M.bbmp[lane] = b_bmps[b]; M.boff[lane] = (uint32_t)b_offs[b] * 2u;
+                        uint64_t ab, bb;
+                        uint32_t ao, bo;
+                        load_block_meta(rma, (uint32_t)(tk >> 32), ab, ao);
+                        load_block_meta(rmb, (uint32_t)tk, bb, bo);
+                        M.abmp[lane] = ab; M.aoff[lane] = ao * 2u;
+                        M.bbmp[lane] = bb; M.boff[lane] = bo * 2u;
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -678,9 +692,9 @@ __device__ __forceinline__ bool tile_lane(uint64_t bmp_uniform, int lane, uint32
 
 template <typename T, int G, int U>
 __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin,
-                                                                        const uint64_t *__restrict__ a_bmps, const uint64_t *__restrict__ a_offs,
-                                                                        const T *__restrict__ a_vals, const uint64_t *__restrict__ b_bmps,
-                                                                        const uint64_t *__restrict__ b_offs, const T *__restrict__ b_vals,
+                                                                        const uint32_t *__restrict__ a_meta, uint32_t a_meta_bytes,
+                                                                        const T *__restrict__ a_vals, const uint32_t *__restrict__ b_meta,
+                                                                        uint32_t b_meta_bytes, const T *__restrict__ b_vals,
                                                                         const uint64_t *__restrict__ c_bmps, const uint64_t *__restrict__ c_offs,
                                                                         typename MacOps<T>::Out *__restrict__ c_vals, uint32_t c_size, uint32_t a_bytes,
                                                                         uint32_t b_bytes)
@@ -691,6 +705,7 @@ __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const ui
     const int w = wave_id(), lane = lane_id();
     const int i = lane >> 3, j = lane & 7;
     const rsrc_t ra = make_rsrc(a_vals, a_bytes), rb = make_rsrc(b_vals, b_bytes);
+    const rsrc_t rma = make_rsrc(a_meta, a_meta_bytes), rmb = make_rsrc(b_meta, b_meta_bytes);
     const uint32_t groups = (c_size + G - 1) / G;
     const uint32_t g0 = blockIdx.x * 4 + w, stride = gridDim.x * 4;
     const uint32_t mine = g0 < groups ? (groups - g0 + stride - 1) / stride : 0u;
@@ -712,9 +727,9 @@ __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const ui
         {
             const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)tbv2, 0), te = (uint32_t)__builtin_amdgcn_readlane((int)tbv2, G);
             if (tb + lane < min(te, tb + 64u)) {
-                const uint32_t a = (uint32_t)(tk2 >> 32), b = (uint32_t)tk2;
-                m_abmp = a_bmps[a]; m_aoff = (uint32_t)a_offs[a] * (uint32_t)sizeof(T);
-                m_bbmp = b_bmps[b]; m_boff = (uint32_t)b_offs[b] * (uint32_t)sizeof(T);
+                load_block_meta(rma, (uint32_t)(tk2 >> 32), m_abmp, m_aoff);
+                load_block_meta(rmb, (uint32_t)tk2, m_bbmp, m_boff);
+                m_aoff *= (uint32_t)sizeof(T); m_boff *= (uint32_t)sizeof(T);
             }
             if (k >= 2 && k - 2 < mine && lane < G) {
                 const uint32_t cc = min((g0 + (k - 2) * stride) * G + (uint32_t)lane, c_size - 1);
@@ -731,9 +746,9 @@ __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const ui
                     w_abmp = 0; w_bbmp = 0; w_aoff = 0; w_boff = 0;
                     if (t + lane < te) {
                         const uint64_t tk = tasks[t + lane];
-                        const uint32_t a = (uint32_t)(tk >> 32), b = (uint32_t)tk;
-                        w_abmp = a_bmps[a]; w_aoff = (uint32_t)a_offs[a] * (uint32_t)sizeof(T);
-                        w_bbmp = b_bmps[b]; w_boff = (uint32_t)b_offs[b] * (uint32_t)sizeof(T);
+                        load_block_meta(rma, (uint32_t)(tk >> 32), w_abmp, w_aoff);
+                        load_block_meta(rmb, (uint32_t)tk, w_bbmp, w_boff);
+                        w_aoff *= (uint32_t)sizeof(T); w_boff *= (uint32_t)sizeof(T);
                     }
                 }
                 T av[U], bv[U];
@@ -789,12 +804,14 @@ void launch_mac_valu(const uint64_t *tasks, const uint32_t *task_begin, bmsp_mat
     uint32_t cs = (uint32_t)C->block_num;
     if (!cs) return;
     const uint64_t a_bytes = (uint64_t)A->values_extent() * sizeof(T), b_bytes = (uint64_t)B->values_extent() * sizeof(T);
-    if (a_bytes < (1ull << 32) && b_bytes < (1ull << 32)) {
+    if (a_bytes < (1ull << 32) && b_bytes < (1ull << 32) && A->block_num < (1ll << 28) && B->block_num < (1ll << 28)) {
+        ensure_block_meta(A, st);
+        ensure_block_meta(B, st);
         const uint32_t groups = (cs + kValuGroupC - 1) / kValuGroupC;
         uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
-        hipLaunchKernelGGL((block_mac_valu_group_kernel<T, kValuGroupC, kValuBatch>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin, A->bmps,
-                           A->offsets, (const T *)A->values, B->bmps, B->offsets, (const T *)B->values, C->bmps, C->offsets,
-                           (typename MacOps<T>::Out *)C->values, cs, (uint32_t)a_bytes, (uint32_t)b_bytes);
+        hipLaunchKernelGGL((block_mac_valu_group_kernel<T, kValuGroupC, kValuBatch>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin, A->block_meta,
+                           (uint32_t)(A->block_num * 16), (const T *)A->values, B->block_meta, (uint32_t)(B->block_num * 16), (const T *)B->values,
+                           C->bmps, C->offsets, (typename MacOps<T>::Out *)C->values, cs, (uint32_t)a_bytes, (uint32_t)b_bytes);
     } else {  // value arrays beyond the 4 GiB a buffer descriptor addresses: pointer-based kernel
         uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)cs + 3) / 4, 256ull * 64);
         hipLaunchKernelGGL((block_mac_valu_kernel<T>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin, A->bmps, A->offsets,
@@ -942,12 +959,14 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
             // the group kernel's 12-byte value loads may run past the last stored value: arrays from this library's
             // allocator carry that slack (runtime.h), borrowed arrays (bmsp_matrix_from_arrays, ownership 2) may not
             const uint32_t a_bytes = (uint32_t)(A->values_extent() * 2), b_bytes = (uint32_t)(B->values_extent() * 2);
-            if (tc_version == 4 && pool_owns(A->values) && pool_owns(B->values)) {
+            if (tc_version == 4 && pool_owns(A->values) && pool_owns(B->values) && A->block_num < (1ll << 28) && B->block_num < (1ll << 28)) {
+                ensure_block_meta(A, st);
+                ensure_block_meta(B, st);
                 uint32_t groups = (c_size + kGroupC - 1) / kGroupC;
                 uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
-                hipLaunchKernelGGL(block_mac_mfma_f16_group_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->bmps, A->offsets,
-                                   (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
-                                   (float *)C->values, c_size, a_bytes + 16u, b_bytes + 16u);
+                hipLaunchKernelGGL(block_mac_mfma_f16_group_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->block_meta,
+                                   (uint32_t)(A->block_num * 16), (const _Float16 *)A->values, B->block_meta, (uint32_t)(B->block_num * 16),
+                                   (const _Float16 *)B->values, C->bmps, C->offsets, (float *)C->values, c_size, a_bytes + 16u, b_bytes + 16u);
             } else {
                 uint32_t groups = ((c_size + 1) / 2 + kPairsPerWave - 1) / kPairsPerWave;
                 uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
