@@ -140,7 +140,7 @@ void device_exclusive_scan(In in, Out out, uint64_t n, hipStream_t st)
 {
     if (n == 0) return;
     uint64_t tiles = (n + kTile - 1) / kTile;
-    if (tiles <= 8) {
+    if (tiles <= 2) {  // a lone workgroup walks short arrays; beyond that three parallel launches beat its serial latency chain
         hipLaunchKernelGGL((scan_tile_down_kernel<T, In, Out>), dim3(1), dim3(kThreads), 0, st, in, out, n,
                            (const T *)nullptr, tiles);
         BMSP_CHECK_LAUNCH();
