@@ -87,7 +87,19 @@ def main():
         import torch  # before the bmsp library: one HIP runtime for both (see pybmsp docstring)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when the communicator comes up; stdout carries exactly one JSON line, so
+        # the banner is sent to stderr (fd-level: the library writes from C)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     import numpy as np
     import pybmsp as B
     from pybmsp import gen
