@@ -186,6 +186,9 @@ static __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint6
 // same digit find each other with one ballot per digit bit, the lowest of them bumps the wave's LDS counter for that
 // digit, and every peer takes (old count + its position among the peers).  Slices, rounds and lanes are all visited
 // in index order, so equal digits keep their input order (stable).
+// The tile is then reordered IN LDS by digit before it leaves: consecutive threads write consecutive destinations, so a
+// digit's run inside the tile (8+ elements on average) goes out as whole 64-byte segments instead of one scattered 8-byte
+// store per key.  Keys and payloads take turns in the same 32 KB staging buffer.
 template <typename P>
 __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t *__restrict__ kin, const P *__restrict__ pin,
                                                                  uint64_t *__restrict__ kout, P *__restrict__ pout, uint32_t n,
@@ -193,7 +196,10 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
                                                                  uint32_t num_tiles)
 {
     __shared__ uint32_t cnt[4][kRadixMaxBins];
-    __shared__ uint32_t dst_base[4][kRadixMaxBins];
+    __shared__ uint32_t local_base[4][kRadixMaxBins];  // first staging slot of (wave, digit)
+    __shared__ uint32_t out_shift[kRadixMaxBins];      // global destination of a digit's run minus its first staging slot
+    __shared__ uint64_t stage[kTile];
+    __shared__ uint32_t scan_lds[4];
     const uint32_t bins = 1u << bits, mask = bins - 1u;
     for (int w = 0; w < 4; w++) {
         cnt[w][threadIdx.x] = 0;
@@ -201,9 +207,11 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
     }
     __syncthreads();
     const int w = wave_id(), lane = lane_id();
-    const uint64_t slice = (uint64_t)blockIdx.x * kTile + (uint64_t)w * (kTile / 4);
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kTile;
+    const uint64_t slice = tile0 + (uint64_t)w * (kTile / 4);
+    const uint32_t tile_n = (uint32_t)min((uint64_t)kTile, (uint64_t)n - tile0);
     uint64_t key[kItems];
-    uint32_t rnk[kItems];
+    uint32_t pos[kItems];  // rank inside (wave, digit), then the staging slot
     const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (int r = 0; r < kItems; r++) {
@@ -224,27 +232,73 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
         int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
         if (valid && lane == leader) old = atomicAdd(&cnt[w][d], (uint32_t)__popcll(peers));
         old = __shfl(old, leader, kWave);
-        rnk[r] = old + (uint32_t)__popcll(peers & lt);
+        pos[r] = old + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < bins; d += kThreads) {
-        uint32_t g = hist_scanned[(uint64_t)d * num_tiles + blockIdx.x];
+    {
+        // thread t owns digits 2t and 2t+1 (one digit when there are <= 256): digit order = thread order for the scan
+        const bool two = bins > (uint32_t)kThreads;
+        const uint32_t d0 = two ? 2u * threadIdx.x : threadIdx.x, d1 = d0 + 1u;
+        uint32_t c0 = 0, c1 = 0;
+        if (d0 < bins) c0 = cnt[0][d0] + cnt[1][d0] + cnt[2][d0] + cnt[3][d0];
+        if (two) c1 = cnt[0][d1] + cnt[1][d1] + cnt[2][d1] + cnt[3][d1];
+        uint32_t total;
+        const uint32_t ex = block_exclusive_sum(c0 + c1, scan_lds, total);
+        if (d0 < bins) {
+            uint32_t g = ex;
+            out_shift[d0] = hist_scanned[(uint64_t)d0 * num_tiles + blockIdx.x] - g;
 #pragma unroll
-        for (int ww = 0; ww < 4; ww++) {
-            dst_base[ww][d] = g;
-            g += cnt[ww][d];
+            for (int ww = 0; ww < 4; ww++) { local_base[ww][d0] = g; g += cnt[ww][d0]; }
+        }
+        if (two) {
+            uint32_t g = ex + c0;
+            out_shift[d1] = hist_scanned[(uint64_t)d1 * num_tiles + blockIdx.x] - g;
+#pragma unroll
+            for (int ww = 0; ww < 4; ww++) { local_base[ww][d1] = g; g += cnt[ww][d1]; }
         }
     }
     __syncthreads();
+    // keys through the staging buffer
 #pragma unroll
     for (int r = 0; r < kItems; r++) {
         uint64_t i = slice + (uint64_t)r * kWave + lane;
         if (i < n) {
             uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-            uint32_t dst = dst_base[w][d] + rnk[r];
-            kout[dst] = key[r];
-            pout[dst] = pin[i];
+            pos[r] += local_base[w][d];
+            stage[pos[r]] = key[r];
         }
+    }
+    __syncthreads();
+    uint32_t dst[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const uint32_t i = (uint32_t)k * kThreads + threadIdx.x;
+        dst[k] = 0;
+        if (i < tile_n) {
+            const uint64_t kk = stage[i];
+            dst[k] = out_shift[(uint32_t)(kk >> shift) & mask] + i;
+            kout[dst[k]] = kk;
+        }
+    }
+    __syncthreads();
+    // payloads through the same buffer
+    P *pstage = reinterpret_cast<P *>(stage);
+    P pv[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        uint64_t i = slice + (uint64_t)r * kWave + lane;
+        if (i < n) pv[r] = pin[i];
+    }
+#pragma unroll
+    for (int r = 0; r < kItems; r++) {
+        uint64_t i = slice + (uint64_t)r * kWave + lane;
+        if (i < n) pstage[pos[r]] = pv[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const uint32_t i = (uint32_t)k * kThreads + threadIdx.x;
+        if (i < tile_n) pout[dst[k]] = pstage[i];
     }
 }
 
