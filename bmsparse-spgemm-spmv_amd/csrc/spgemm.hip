@@ -893,12 +893,12 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     PingPong<uint64_t> kk{k0.p, k1.p}, vv{v0.p, v1.p};
     // The tasks leave the expansion grouped by block-row of A (A's blocks are key-ordered), so only the column bits need
     // sorting inside each block-row segment.  The segmented sort keeps a whole segment in LDS (segsort.hip); it wins when
-    // segments are long enough to fill a wave yet none exceeds a workgroup's LDS (cage-like rows: 355 vs 704 us); tiny segments
-    // (banded, 9 tasks per block-row: 143 vs 121 us) and hub rows (power-law) are faster through the global radix sort on the packed key.  AUTO decides on the average
+    // segments are long enough to fill a wave yet none exceeds a workgroup's LDS (cage-like rows: 289 vs 410 us; banded, 9 tasks
+    // per block-row: 92 vs 121 us); hub rows (power-law) are faster through the global radix sort on the packed key.  AUTO decides on the average
     // segment length -- the reference decides on the task count alone (:963) -- and falls back when a hub row shows up.
     const uint64_t a_block_rows = (uint64_t)A->num_block_rows();
     const uint64_t avg_seg = n_tasks / (a_block_rows ? a_block_rows : 1);
-    const bool try_segmented = mode == BMSP_SORT_SEGMENTED || (mode == BMSP_SORT_AUTO && avg_seg >= 64 && avg_seg <= 2048);
+    const bool try_segmented = mode == BMSP_SORT_SEGMENTED || (mode == BMSP_SORT_AUTO && avg_seg >= 4 && avg_seg <= 2048);
     S->sort_path = 0;
     if (n_tasks) {
         if (try_segmented && segsort_tasks_by_column(kk, vv, n_tasks, jbits, st)) {
