@@ -196,6 +196,8 @@ def main():
         out["spgemm"] = bench_spgemm(B, gen, np, args)
     if use_dist and not args.skip_spgemm:
         out["spgemm_sharded"] = bench_spgemm_sharded(B, gen, np, torch, dist, rank, world)
+    if use_dist:
+        out["spmv_sharded"] = bench_spmv_sharded(B, np, torch, dist, rank, world, mats[0], x, ys[0])
 
     # ---------------- vendor comparison column (rocSPARSE CSR on the same matrices; reporting only) ----------------
     if rank == 0 and not use_dist and not args.skip_vendor:
@@ -302,6 +304,29 @@ def scalar_products(np, A):
     r, c, _ = A.to_coo()
     rownnz = np.bincount(r, minlength=A.num_rows)
     return int(rownnz[c].sum())
+
+
+def bench_spmv_sharded(B, np, torch, dist, rank, world, A, x, y_whole):
+    """SURVEY 8(e), SpMV row: ONE matrix cut into nnz-balanced block-row panels, x replicated, y slices all-gathered (strong
+    scaling; the headline `value` above is the weak-scaling replica rate)."""
+    from pybmsp import shard
+    bounds = shard.spmv_row_bounds(A, world)
+    full, st = shard.spmv_sharded(A, x, rank, world, dist, torch, bounds)  # warm-up, and the check below
+    ref = torch.empty_like(full)
+    B.check(B.lib().bmsp_memcpy_d2d(ref.data_ptr(), y_whole.ptr, full.numel() * full.element_size()))
+    same = bool(torch.equal(full, ref))
+    reps = 20
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    gather_ms = 0.0
+    for _ in range(reps):
+        full, st = shard.spmv_sharded(A, x, rank, world, dist, torch, bounds)
+        gather_ms += st["gather_ms"]
+    torch.cuda.synchronize(); dist.barrier()
+    ms = (time.perf_counter() - t0) * 1e3 / reps
+    return {"workload": "one matrix, row panels balanced by nnz, y all-gathered", "scaling": "strong", "n_gpus": world,
+            "ms_per_product": round(ms, 4), "allgather_ms": round(gather_ms / reps, 4), "allgather_bytes": st["gather_bytes"],
+            "matches_single_gpu_sweep": same}
 
 
 def bench_spgemm_sharded(B, gen, np, torch, dist, rank, world):

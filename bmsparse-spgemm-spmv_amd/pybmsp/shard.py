@@ -91,3 +91,47 @@ def spgemm_sharded(A, Bt, rank, world, dist, torch, tc_version=5, mode=0):
     stats = {"tasks": int(st["surviving_tasks"]), "gather_bytes": int(nbytes), "gather_ms": gather_ms,
              "bounds": [int(x) for x in bounds], "panel": st}
     return B.BmSpMatrix(h.value), stats
+
+
+def balanced_bounds(work_per_row, parts):
+    """block-row bounds [b_0 = 0, ..., b_parts = nbr]: panel p ends at the first block-row where the cumulative work reaches
+    p / parts of the total (the rule of bmsp_partition_rows, csrc/shard.hip, on a host array)."""
+    work = np.asarray(work_per_row, dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(work)])
+    total = int(cum[-1])
+    bounds = [0]
+    for p in range(1, parts):
+        r = int(np.searchsorted(cum, total * p // parts, side="left"))
+        bounds.append(max(min(r, len(work)), bounds[-1]))
+    bounds.append(len(work))
+    return bounds
+
+
+def spmv_row_bounds(A, parts):
+    """SURVEY.md 8(e), SpMV: block-row panels balanced by stored values (nnz)."""
+    rowptr = A.block_row_ptr().astype(np.int64)
+    offsets = A.host_arrays()[2].astype(np.int64)
+    return balanced_bounds(np.diff(offsets[rowptr]), parts)
+
+
+def spmv_sharded(A, x, rank, world, dist, torch, bounds=None):
+    """y = A x with A cut into block-row panels (x replicated): every rank sweeps its panel, the y slices are exchanged with one
+    padded all-gather, and every rank returns the whole y as a CUDA tensor.  No collective touches the sweep itself."""
+    import pybmsp as B
+    info = A.info()
+    if bounds is None:
+        bounds = spmv_row_bounds(A, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    view = A.row_panel(lo, hi)
+    y = B.spmv(view, x)  # rows outside the panel come out as zeros
+    r0, r1 = min(lo * 8, info["num_rows"]), min(hi * 8, info["num_rows"])
+    tdt = torch.float64 if info["dtype"] == B.F64 else torch.float32
+    mine = torch.empty(r1 - r0, dtype=tdt, device="cuda")
+    if r1 > r0:
+        B.check(B.lib().bmsp_memcpy_d2d(mine.data_ptr(), y.ptr + r0 * y.dtype.itemsize, (r1 - r0) * y.dtype.itemsize))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gathered, nbytes = allgatherv([mine], dist, torch)
+    full = torch.cat([g[0] for g in gathered])
+    torch.cuda.synchronize()
+    return full, {"gather_ms": (time.perf_counter() - t0) * 1e3, "gather_bytes": int(nbytes), "bounds": [int(b) for b in bounds]}

@@ -81,6 +81,58 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _spmv_worker(rank, world, port, out_dir):
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(repo, "bmsparse-spgemm-spmv_amd"))
+    sys.path.insert(0, os.path.join(repo, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import oracle as O
+    from pybmsp import gen, shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, _, r, c, v = gen.rmat(10, 5, seed=4)
+    n_rows = n - 3  # ragged last block-row
+    keep = r < n_rows
+    A = O.bmsp_from_coo(O.Coo(n_rows, n, r[keep], c[keep], v[keep]), O.F32, False)
+    x = gen.spmv_x(n, "cusp")
+    whole = O.spmv_f32(A, x)
+    nbr = (n_rows + 7) // 8
+    a_rows = (A.keys >> np.uint64(32)).astype(np.int64)
+    nnz_per_block = np.diff(A.offsets.astype(np.int64))
+    work = np.bincount(a_rows, weights=nnz_per_block, minlength=nbr).astype(np.int64)
+    bounds = shard.balanced_bounds(work, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    sel = (a_rows >= lo) & (a_rows < hi)
+    first = int(np.argmax(sel)) if sel.any() else 0
+    cnt = int(sel.sum())
+    o0 = int(A.offsets[first]) if cnt else 0
+    o1 = int(A.offsets[first + cnt]) if cnt else 0
+    panel = O.Bmsp(n_rows, n, O.F32, 0, A.keys[sel], A.bmps[sel], A.offsets[first:first + cnt + 1] - np.uint64(o0), A.values[o0:o1])
+    y = O.spmv_f32(panel, x)
+    r0, r1 = min(lo * 8, n_rows), min(hi * 8, n_rows)
+    assert not y[:r0].any() and not y[r1:].any()
+    gathered, nbytes = shard.allgatherv([torch.from_numpy(np.ascontiguousarray(y[r0:r1]))], dist, torch)
+    full = np.concatenate([g[0].numpy() for g in gathered])
+    ok = full.shape == whole.shape and np.array_equal(full, whole)
+    with open(os.path.join(out_dir, "spmv_rank%d.txt" % rank), "w") as f:
+        f.write("%d %d %d\n" % (int(ok), nbytes, int(work[lo:hi].sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_spmv_exchange_world2(tmp_path):
+    """SURVEY 8(e), SpMV row: nnz-balanced block-row panels, x replicated, one padded all-gather of the y slices."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_spmv_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [open(tmp_path / ("spmv_rank%d.txt" % r)).read().split() for r in range(2)]
+    assert all(r[0] == "1" for r in res), res
+    assert res[0][1] == res[1][1] and int(res[0][1]) > 0
+    w0, w1 = int(res[0][2]), int(res[1][2])
+    assert abs(w0 - w1) <= 0.35 * (w0 + w1)
+
+
 def test_sharded_spgemm_exchange_world2(tmp_path):
     import torch.multiprocessing as mp
     port = _free_port()
