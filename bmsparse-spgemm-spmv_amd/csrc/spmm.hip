@@ -114,6 +114,185 @@ __global__ __launch_bounds__(kThreads) void spmm_kernel(const SweepItem *__restr
     }
 }
 
+// ---- k > 16: one lane per vector, tiles walked by the whole wave ----------------------------------------------------
+// The slot kernel above keeps 64/KK tiles in flight per wave, which is one for KK = 64: every tile then costs two dependent
+// round trips (its words, then its values and X rows).  Here the tile words are fetched lane-parallel, 64 tiles per batch
+// (three coalesced streams, as in the SpMV sweep); each lane decodes its tile's stored elements into a flat ELEMENT STREAM in
+// LDS (column, value index, row; positions from a wave prefix sum of the popcounts), and the wave then walks the stream sixteen
+// elements at a time: sixteen X rows (lane j reads X[col][j], one coalesced request per element) and sixteen values are
+// requested before the first product, whatever tiles the elements came from.  Block-rows arrive in order, so eight row accumulators per
+// lane suffice; they are stored whenever the stream moves to the next block-row.
+template <typename A>
+__device__ __forceinline__ void acc_row(A (&acc)[8], uint32_t r, A a, A x)
+{
+    switch (r) {  // r is wave-uniform: a scalar branch, each arm one FMA on a fixed register
+    case 0: acc[0] = fma_acc(a, x, acc[0]); break;
+    case 1: acc[1] = fma_acc(a, x, acc[1]); break;
+    case 2: acc[2] = fma_acc(a, x, acc[2]); break;
+    case 3: acc[3] = fma_acc(a, x, acc[3]); break;
+    case 4: acc[4] = fma_acc(a, x, acc[4]); break;
+    case 5: acc[5] = fma_acc(a, x, acc[5]); break;
+    case 6: acc[6] = fma_acc(a, x, acc[6]); break;
+    default: acc[7] = fma_acc(a, x, acc[7]); break;
+    }
+}
+
+constexpr uint32_t kStreamCap = 512;  // stored elements decoded per pass of the element stream
+
+struct StreamEntry {  // 16 bytes: one ds_read_b128
+    uint32_t col, vidx, rowid, pad;  // column of X, index into values, (block-row << 3) | tile row
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void spmm_wide_kernel(const SweepItem *__restrict__ items, uint32_t num_items, const uint64_t *__restrict__ keys,
+                                                             const uint64_t *__restrict__ bmps, const uint64_t *__restrict__ offsets,
+                                                             const T *__restrict__ values, const T *__restrict__ X,
+                                                             typename Acc<T>::type *__restrict__ Y, typename Acc<T>::type *__restrict__ carry,
+                                                             uint32_t *__restrict__ counters, uint32_t num_rows, uint32_t num_cols, uint32_t k,
+                                                             uint64_t ldx, uint64_t ldy)
+{
+    using A = typename Acc<T>::type;
+    constexpr int KK = 64;
+    __shared__ StreamEntry s_entries[4][kStreamCap];
+    const int w = wave_id(), lane = lane_id();
+    const uint32_t item_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
+    if (item_id >= num_items) return;
+    StreamEntry *ent = s_entries[w];
+    const SweepItem it = items[item_id];
+    const uint32_t j = blockIdx.y * KK + (uint32_t)lane;
+    const bool jok = j < k;
+    const bool is_long = it.num_items != 0;
+    A acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) acc[r] = A(0);
+    uint32_t cur_row = it.row_begin;
+    // stores block-row cur_row and zero-fills the block-rows up to (not including) next_row -- short items own their rows
+    auto flush_to = [&](uint32_t next_row) {
+        if (!is_long && jok) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t row = cur_row * 8u + (uint32_t)r;
+                if (row < num_rows) Y[(uint64_t)row * ldy + j] = acc[r];
+            }
+            for (uint32_t br = cur_row + 1; br < next_row; br++) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const uint32_t row = br * 8u + (uint32_t)r;
+                    if (row < num_rows) Y[(uint64_t)row * ldy + j] = A(0);
+                }
+            }
+        }
+    };
+    for (uint32_t base = it.blk_begin; base < it.blk_end; base += 64) {
+        // lane-per-tile: the three streamed words, and the tile's place in the element stream
+        const uint32_t b = base + (uint32_t)lane;
+        uint64_t bm = 0, key = (uint64_t)it.row_begin << 32;
+        uint32_t off = 0;
+        if (b < it.blk_end) { bm = bmps[b]; key = keys[b]; off = (uint32_t)offsets[b]; }
+        const uint32_t cnt = (uint32_t)__popcll(bm);
+        uint32_t incl = cnt;  // inclusive prefix sum over lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t q = (uint32_t)__shfl_up((int)incl, d, kWave);
+            if (lane >= d) incl += q;
+        }
+        const uint32_t excl = incl - cnt;
+        uint32_t first_lane = 0;  // tiles [first_lane, ...) still to be streamed
+        while (first_lane < 64u) {
+            // the longest run of tiles from first_lane whose elements fit the staging buffer (one tile always fits)
+            const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)first_lane);
+            const uint64_t fits = __ballot(incl - start <= kStreamCap && (uint32_t)lane >= first_lane);
+            const uint32_t end_lane = first_lane + (uint32_t)__popcll(fits);  // fits is a contiguous run (incl is monotone)
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(end_lane - 1)) - start;
+            __builtin_amdgcn_wave_barrier();
+            if ((uint32_t)lane >= first_lane && (uint32_t)lane < end_lane) {
+                uint64_t m = bm;
+                uint32_t e = excl - start, v = off;
+                const uint32_t rbase = key_row(key) << 3, cbase = key_col(key) * 8u;
+                while (m) {
+                    const uint32_t p = (uint32_t)__clzll((long long)m);
+                    m &= ~(0x8000000000000000ull >> p);
+                    ent[e++] = StreamEntry{cbase + (p & 7u), v++, rbase | (p >> 3), 0u};
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the stream: kChunk X rows and values requested before the first product.  (Overlapping the requests of the next
+            // chunk with the products of this one was measured slower: with the row-change stores in the product phase the
+            // compiler's wait-count analysis falls back to draining every load, and the code doubles.)
+            constexpr int kChunk = 16;
+            for (uint32_t e0 = 0; e0 < total; e0 += kChunk) {
+                A av[kChunk], xv[kChunk];
+                uint32_t rid[kChunk];
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    if (e0 + u < total) {
+                        const StreamEntry en = ent[e0 + u];  // same address in every lane: an LDS broadcast
+                        rid[u] = en.rowid;
+                        av[u] = (A)values[en.vidx];
+                        xv[u] = (en.col < num_cols && jok) ? (A)X[(uint64_t)en.col * ldx + j] : A(0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    if (e0 + u < total) {
+                        const uint32_t rowid = (uint32_t)__builtin_amdgcn_readfirstlane((int)rid[u]);
+                        if ((rowid >> 3) != cur_row) {
+                            flush_to(rowid >> 3);
+                            cur_row = rowid >> 3;
+#pragma unroll
+                            for (int r = 0; r < 8; r++) acc[r] = A(0);
+                        }
+                        acc_row<A>(acc, rowid & 7u, av[u], xv[u]);
+                    }
+                }
+            }
+            first_lane = end_lane;
+        }
+    }
+    flush_to(it.row_end);
+    if (!is_long) return;
+    // hub block-row: park the partial rows, the last arriver of this (row, vector chunk) folds them in item order
+    const size_t slot = ((size_t)item_id * gridDim.y + blockIdx.y) * 8 * KK;
+#pragma unroll
+    for (int r = 0; r < 8; r++) __hip_atomic_store(&carry[slot + (size_t)r * KK + lane], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t ticket = 0;
+    uint32_t *cnt_p = counters + (size_t)it.long_idx * gridDim.y + blockIdx.y;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(cnt_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != it.num_items - 1) return;
+#pragma unroll
+    for (int r = 0; r < 8; r++) acc[r] = A(0);
+    for (uint32_t c = 0; c < it.num_items; c++) {
+        const size_t src = ((size_t)(it.first_item + c) * gridDim.y + blockIdx.y) * 8 * KK;
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc[r] += __hip_atomic_load(&carry[src + (size_t)r * KK + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (jok) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t row = it.row_begin * 8u + (uint32_t)r;
+            if (row < num_rows) Y[(uint64_t)row * ldy + j] = acc[r];
+        }
+    }
+}
+
+template <typename T>
+void launch_wide(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, int k, hipStream_t st)
+{
+    using Ac = typename Acc<T>::type;
+    const uint32_t n_items = (uint32_t)A->spmv_num_chunks;
+    const uint32_t chunks = (uint32_t)((k + 63) / 64);
+    DevBuf<Ac> carry(A->spmv_plan_long ? (size_t)n_items * chunks * 8 * 64 : 1);
+    DevBuf<uint32_t> counters((size_t)(A->spmv_plan_long ? A->spmv_plan_long : 1) * chunks);
+    BMSP_HIP(hipMemsetAsync(counters.p, 0, 4 * counters.n, st));
+    hipLaunchKernelGGL((spmm_wide_kernel<T>), dim3((n_items + 3) / 4, chunks), dim3(kThreads), 0, st, plan_items(A), n_items, A->keys, A->bmps, A->offsets,
+                       (const T *)A->values, (const T *)X, (Ac *)Y, carry.p, counters.p, (uint32_t)A->num_rows, (uint32_t)A->num_cols, (uint32_t)k,
+                       (uint64_t)ldx, (uint64_t)ldy);
+    BMSP_CHECK_LAUNCH();
+    if (A->spmv_plan_long) BMSP_HIP(hipStreamSynchronize(st));  // the carry slots go back to the pool on return
+}
+
 template <typename T, int KK>
 void launch_kk(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, int k, hipStream_t st)
 {
@@ -138,6 +317,7 @@ void launch(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, 
     // serially), so the widest lane group that k fills wins
     if (k <= 4) launch_kk<T, 4>(A, X, ldx, Y, ldy, k, st);
     else if (k <= 16) launch_kk<T, 16>(A, X, ldx, Y, ldy, k, st);
+    else if ((uint64_t)A->values_extent() < (1ull << 32)) launch_wide<T>(A, X, ldx, Y, ldy, k, st);  // 32-bit value indices in the stream
     else launch_kk<T, 64>(A, X, ldx, Y, ldy, k, st);
 }
 
