@@ -3,7 +3,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; CASE=${2:-cage}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-P=$GRAFT_REPO_ROOT/tools_spgemm_stages.py
+P=$GRAFT_REPO_ROOT/tools/spgemm_stages.py
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $P $CASE > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq1 -- python3 $P $CASE > $OUT/pmc_sq1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $P $CASE > $OUT/pmc_fetch.log 2>&1

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """experiment helper: SpGEMM stage times for the bench matrices under both sort modes / MAC kernels"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "bmsparse-spgemm-spmv_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bmsparse-spgemm-spmv_amd"))
 import numpy as np, pybmsp as B
 from pybmsp import gen
 cases = [("banded(101492,8)", gen.banded(101492, 8)), ("cage_like(130228)", gen.cage_like(130228)), ("rmat(16,8)", gen.rmat(16, 8))]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """experiment helper: SpMM throughput against k single-vector sweeps"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "bmsparse-spgemm-spmv_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bmsparse-spgemm-spmv_amd"))
 import numpy as np, pybmsp as B
 from pybmsp import gen
 n, _, r, c, v = gen.rmat(20, 2)

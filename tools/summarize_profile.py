@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses a tools_profile.sh output directory (gpurun_out/<name>) into profiles/<tag>_*.{csv,md} (tracked)."""
+"""Condenses a tools/profile.sh output directory (gpurun_out/<name>) into profiles/<tag>_*.{csv,md} (tracked)."""
 import csv, glob, collections, os, shutil, sys
 
 src, tag, kern = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "spmv_sweep")
