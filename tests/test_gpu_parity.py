@@ -280,7 +280,7 @@ def test_spgemm_fixtures_square(oracle, bmsp, path, dtype, tc):
         check_spgemm(oracle, bmsp, t, t, dtype, mode, tc, exact_expected=True)
 
 
-@pytest.mark.parametrize("case", ["rect", "banded", "rmat", "empty_rows", "filtered", "single_block", "wide", "long_segments"])
+@pytest.mark.parametrize("case", ["rect", "banded", "rmat", "empty_rows", "filtered", "single_block", "wide", "long_segments", "hub_c_blocks"])
 @pytest.mark.parametrize("dtype,tc", [(0, 5), (1, 5), (1, 4), (2, 5)])
 def test_spgemm_synthetic(oracle, bmsp, case, dtype, tc):
     from pybmsp import gen
@@ -305,6 +305,15 @@ def test_spgemm_synthetic(oracle, bmsp, case, dtype, tc):
         rc, first = np.unique(np.concatenate([r1, r2]) * 400 + np.concatenate([c1, c2]), return_index=True)
         A = (64, 400, rc // 400, rc % 400, np.concatenate([v1, v2])[first])
         B = gen.random_coo(400, 3000, 12000, seed=10, lo=0, hi=1)
+    elif case == "hub_c_blocks":
+        # C(0,0) and C(0,1) collect 300 tasks each (runs that cross several 64-task waves of the bitmap pass and several
+        # 64-task windows of the block-MAC), next to ordinary short runs
+        ra, ca = np.meshgrid(np.arange(8), np.arange(0, 2400, 3), indexing="ij")
+        rb, cb = np.meshgrid(np.arange(0, 2400, 5), np.arange(16), indexing="ij")
+        _, _, r2, c2, v2 = gen.random_coo(64, 2400, 700, seed=11, lo=0, hi=1)
+        rc, first = np.unique(np.concatenate([ra.ravel(), r2]) * 2400 + np.concatenate([ca.ravel(), c2]), return_index=True)
+        A = (64, 2400, rc // 2400, rc % 2400, np.concatenate([np.ones(ra.size), v2])[first])
+        B = (2400, 16, rb.ravel(), cb.ravel(), np.ones(rb.size) * 0.5)
     elif case == "filtered":
         # A uses only even k, B only odd k inside every tile: every candidate pair dies in the bitmap filter
         n = 256
