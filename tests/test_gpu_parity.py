@@ -329,6 +329,28 @@ def test_spgemm_synthetic(oracle, bmsp, case, dtype, tc):
         assert st["surviving_tasks"] == 0 and st["c_blocks"] == 0 and st["bmp_reduction"] == st["task_list_size"] > 0
 
 
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_spgemm_randomized_differential(oracle, bmsp, seed):
+    """seeded random shapes / densities / value types against the oracle: exercises group and window boundaries of the
+    block-MAC kernels (C block counts mod 4 and mod 16, task lists around 64), empty operands, single rows and columns."""
+    from pybmsp import gen
+    rng = np.random.default_rng(1000 + seed)
+    m, k, n = (int(rng.integers(1, 260)) for _ in range(3))
+    if seed % 6 == 0:
+        m = int(rng.integers(1, 9))        # a single block-row
+    if seed % 6 == 1:
+        n = int(rng.integers(1, 9))        # a single block-column
+    dens = float(rng.choice([0.002, 0.02, 0.1, 0.5]))
+    nnz_a = int(m * k * dens * rng.uniform(0.3, 1.5)); nnz_b = int(k * n * dens * rng.uniform(0.3, 1.5))
+    if seed == 5:
+        nnz_b = 0                           # empty B
+    A = gen.random_coo(m, k, nnz_a, seed=2 * seed + 1, lo=0, hi=1)
+    B = gen.random_coo(k, n, nnz_b, seed=2 * seed + 2, lo=0, hi=1)
+    dtype, tc = [(0, 5), (1, 5), (1, 4), (2, 5), (1, 2)][seed % 5]
+    for mode in (0, 1, 2):
+        check_spgemm(oracle, bmsp, A, B, dtype, mode, tc)
+
+
 def test_spgemm_chain_feeds_back(oracle, bmsp):
     """C is a valid A operand (normal layout, keys ascending): (A*A)*A runs and matches the oracle chain."""
     from pybmsp import gen
