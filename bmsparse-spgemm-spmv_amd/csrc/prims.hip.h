@@ -302,6 +302,25 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
     }
 }
 
+// bitonic network on P (power of two) machine words held in LDS; every participating thread calls it with the same P
+template <typename W, int THREADS, bool BLOCK_SYNC>
+__device__ __forceinline__ void bitonic_words(W *a, uint32_t P, uint32_t tid)
+{
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t p = tid; p < P / 2; p += THREADS) {
+                const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const uint32_t q = i | j;
+                const W x = a[i], y = a[q];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { a[i] = y; a[q] = x; }
+            }
+            if (BLOCK_SYNC) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 template <typename T>
 struct PingPong {
     T *cur;

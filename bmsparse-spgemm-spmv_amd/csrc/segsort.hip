@@ -351,24 +351,6 @@ void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kTaskWaveMax = 1024, kTaskWaveIdxBits = 10, kTaskBlockIdxBits = 12;
 
-template <typename W, int THREADS, bool BLOCK_SYNC>
-__device__ __forceinline__ void bitonic_words(W *a, uint32_t P, uint32_t tid)
-{
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t p = tid; p < P / 2; p += THREADS) {
-                const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                const uint32_t q = i | j;
-                const W x = a[i], y = a[q];
-                const bool up = (i & k) == 0;
-                if ((x > y) == up) { a[i] = y; a[q] = x; }
-            }
-            if (BLOCK_SYNC) __syncthreads();
-            else __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
 template <typename W, int THREADS, bool BLOCK_SYNC, uint32_t IDX_BITS>
 __device__ __forceinline__ void sort_task_segment(W *a, uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, uint64_t lo, uint32_t len, uint32_t p_min,
                                                   uint64_t col_mask, uint32_t tid)

@@ -10,13 +10,13 @@ for name, (n, _, r, c, v) in cases:
     for dtype, tc in ((B.F32, 5), (B.F16, 5), (B.F16, 4)):
         A = B.BmSpMatrix.from_coo(n, n, r, c, v, dtype=dtype)
         At = B.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=dtype)
-        for mode in (2, 1):
+        for mode in (2, 1, 0):
             best = None
             for it in range(3):
                 Cm, st = B.spgemm(A, At, mode=mode, tc_version=tc)
                 if it and (best is None or st["t_us"][0] < best["t_us"][0]): best = st
                 del Cm
             t = best["t_us"]
-            print("%-18s dt=%d tc=%d mode=%d tasks=%9d surv=%9d C=%8d | total %8.0f us | T2 %5.0f T3 %6.0f T4 %6.0f T5 %7.0f T6 %5.0f T9 %6.0f T7 %7.0f | MAC %.2f TF/s" % (
-                name, dtype, tc, mode, best["task_list_size"], best["surviving_tasks"], best["c_blocks"], t[0], t[2], t[3], t[4], t[5], t[6], t[9], t[7],
+            print("%-18s dt=%d tc=%d mode=%d path=%d tasks=%9d surv=%9d C=%8d | total %8.0f us | T2 %5.0f T3 %6.0f T4 %6.0f T5 %7.0f T6 %5.0f T9 %6.0f T7 %7.0f | MAC %.2f TF/s" % (
+                name, dtype, tc, mode, best["sort_path"], best["task_list_size"], best["surviving_tasks"], best["c_blocks"], t[0], t[2], t[3], t[4], t[5], t[6], t[9], t[7],
                 1024.0 * best["surviving_tasks"] / max(t[7], 1e-9) / 1e6))
