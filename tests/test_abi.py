@@ -58,6 +58,18 @@ def test_host_bit_helpers_against_bruteforce(tmp_path):
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout
 
 
+def _build_cpp_api_check(out_path):
+    lib_dir = os.path.join(REPO, "bmsparse-spgemm-spmv_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I" + os.path.join(REPO, "include"), os.path.join(REPO, "tests", "cpp_api_check.cpp"),
+                           "-o", out_path, "-L" + lib_dir, "-lbmsp", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_cpp_headers_compile_and_link(tmp_path):
+    """include/bmSpMatrix.h + include/CSRMatrix.h: every template the reference's mains and checks use instantiates and links
+    against libbmsp.so with a plain host compiler (no HIP headers on the include path)."""
+    _build_cpp_api_check(str(tmp_path / "cpp_api_check"))
+
+
 def test_generators_are_deterministic():
     from pybmsp import gen
     n, _, r, c, v = gen.rmat(10, 4, seed=1)

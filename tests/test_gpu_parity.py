@@ -613,6 +613,28 @@ def test_borrowed_arrays_multiply(oracle, bmsp):
 # ---------------------------------------------------------------------------------------------------------
 # drop-in executables and batch scripts (boundary: argv + stdout contract)
 # ---------------------------------------------------------------------------------------------------------
+def test_cpp_api_surface(tmp_path, bmsp):
+    """the reference's C++ surface end to end on data/real (known answers of tests/golden/ragusa16_known.json)."""
+    import subprocess
+    import test_abi
+    exe = str(tmp_path / "cpp_api_check")
+    test_abi._build_cpp_api_check(exe)
+    folder = os.path.join(MTX, "real")
+    out = subprocess.run([exe, os.path.join(folder, "A_matrix.mtx"), os.path.join(folder, "B_matrix.mtx")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = {l.split()[1]: l.split()[2:] for l in out.stdout.splitlines() if l.startswith("CHECK")}
+    A = bmsp.BmSpMatrix.from_mtx(os.path.join(folder, "A_matrix.mtx"))
+    assert [int(x) for x in lines["A"]] == [24, 24, A.nnz, 9]
+    assert [int(x) for x in lines["adopted"]] == [A.nnz, 9, 0, 0]        # the vectors were adopted (left empty)
+    assert lines["compare"] == ["Final:", "0"]
+    assert float(lines["spmv"][0]) == 109.0                              # sum of y = A*1 (BASELINE.md 2)
+    assert float(lines["spmm"][0]) == 3 * 109.0
+    assert lines["mult"] == ["9", "255", "1070", "27"]
+    Cm = bmsp.CSRMatrix.from_mtx(os.path.join(folder, "A_matrix.mtx")).multiply(bmsp.CSRMatrix.from_mtx(os.path.join(folder, "B_matrix.mtx")))
+    nr, nc, ro, cols, vals = Cm.arrays()
+    assert [int(lines["csr"][0]), int(lines["csr"][1])] == [nr, len(cols)] and float(lines["csr"][2]) == float(np.sum(vals.astype(np.float64)))
+
+
 def test_cli_executables_and_batch_scripts(tmp_path):
     import shutil
     import subprocess
