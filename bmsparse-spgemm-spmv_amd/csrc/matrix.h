@@ -24,6 +24,7 @@ struct bmsp_matrix_s {
     uint32_t *spmv_chunks = nullptr;
     int64_t spmv_num_chunks = 0;
     int64_t spmv_plan_long = 0;
+    int64_t spmv_full_tiles = 0;  // tiles with all 64 values stored (decides the sweep variant)
     size_t spmv_plan_off_cnt = 0, spmv_plan_off_carry = 0;
     // (bitmap, value offset) of every block as one 16-byte record, for kernels that gather both (block-MAC): built lazily
     uint32_t *block_meta = nullptr;  // block_num x {bmp lo, bmp hi, offset in elements, 0}

@@ -71,6 +71,11 @@ struct PlanTotals {
         if (i == n) *out = ex;
     }
 };
+struct FullTileIn {
+    const uint64_t *bmps;
+    uint64_t n;
+    __device__ uint64_t operator()(uint64_t b) const { return (b < n && bmps[b] == ~0ull) ? 1ull : 0ull; }
+};
 struct PlanFill {
     RowClass rc;
     uint32_t nb;
@@ -133,7 +138,9 @@ void build_plan(bmsp_matrix_s *A, hipStream_t st)
     uint32_t hdr[4] = {n_items, n_long, (uint32_t)off_cnt, (uint32_t)off_carry};
     BMSP_HIP(hipMemcpyAsync(mem, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
     if (nbr) device_exclusive_scan<uint64_t>(rc, PlanFill{rc, nb, (SweepItem *)(mem + off_items)}, (uint64_t)nbr + 1, st);
-    BMSP_HIP(hipStreamSynchronize(st));
+    HostScalar<uint64_t> full_h;
+    device_exclusive_scan<uint64_t>(FullTileIn{A->bmps, nb}, PlanTotals{nb, full_h.dev()}, (uint64_t)nb + 1, st);
+    A->spmv_full_tiles = (int64_t)full_h.wait(st);
     A->spmv_chunks = (uint32_t *)mem;
     A->spmv_num_chunks = n_items;
     A->spmv_plan_long = n_long;
@@ -170,12 +177,45 @@ struct Buf<double> {
     static __device__ __forceinline__ double ld(rsrc_t r, uint32_t off) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); }
 };
 
+// four consecutive elements with one buffer load (16 bytes for float): the full-tile path below
+template <typename T>
+struct Buf4;
+template <>
+struct Buf4<float> {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void ld(rsrc_t r, uint32_t off, float (&o)[4])
+    {
+        const v4 v = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+};
+template <>
+struct Buf4<_Float16> {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void ld(rsrc_t r, uint32_t off, float (&o)[4])
+    {
+        const h4 v = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+        o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+    }
+};
+template <>
+struct Buf4<double> {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ void ld(rsrc_t r, uint32_t off, double (&o)[4])
+    {
+        const d2 a = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        const d2 b = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, off + 16u, 0, 0));
+        o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1];
+    }
+};
+
 constexpr int kSparseMax = 8;   // tiles with more stored values than this go to the wave-wide dense pass
 constexpr int kInlineSlots = 2; // stored values of a tile handled in the streaming loop; the rest of a tile waits in a queue
                                 // (1, 2 and 3 measure the same within 2 %)
 constexpr int kDenseTrip = 8;   // dense tiles per trip of the wave-wide pass
 constexpr uint32_t kLeftCap = 128;  // leftover queue: flushed 64 tiles at a time, so every lane has work
 constexpr uint32_t kDenseCap = 64;  // dense queue, swept after each half batch
+constexpr int kFullTrip = 4;        // FULL tiles (all 64 values stored): 4 tiles per wave step x kFullTrip steps in flight
 
 template <typename A>
 __device__ __forceinline__ void lds_add(A *p, A v)
@@ -222,7 +262,9 @@ __device__ __forceinline__ uint64_t peel_tile(uint64_t bm, uint32_t voff, uint32
     return bm;
 }
 
-template <typename T>
+// FULL: matrices whose plan counted many full tiles (FEM-like) get the variant with the 16-byte-per-lane full-tile pass; the
+// graph-like default keeps the leaner code (the extra pass costs the webbase-like case 7 % even when it never runs)
+template <typename T, bool FULL>
 __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *__restrict__ items, uint32_t num_items,
                                                               const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bmps,
                                                               const uint64_t *__restrict__ offsets, const T *__restrict__ values,
@@ -236,6 +278,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
     __shared__ uint64_t l_bmp_all[4][kLeftCap], d_bmp_all[4][kDenseCap];
     __shared__ uint32_t l_off_all[4][kLeftCap], l_xb_all[4][kLeftCap], l_tb_all[4][kLeftCap];
     __shared__ uint32_t d_off_all[4][kDenseCap], d_xb_all[4][kDenseCap], d_tb_all[4][kDenseCap];
+    __shared__ uint32_t f_off_all[4][kDenseCap], f_xb_all[4][kDenseCap], f_tb_all[4][kDenseCap];
     const int w = wave_id(), lane = lane_id();
     const uint32_t item_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
     if (item_id >= num_items) return;
@@ -243,6 +286,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
     uint64_t *l_bmp = l_bmp_all[w], *d_bmp = d_bmp_all[w];
     uint32_t *l_off = l_off_all[w], *l_xb = l_xb_all[w], *l_tb = l_tb_all[w];
     uint32_t *d_off = d_off_all[w], *d_xb = d_xb_all[w], *d_tb = d_tb_all[w];
+    uint32_t *f_off = f_off_all[w], *f_xb = f_xb_all[w], *f_tb = f_tb_all[w];
     const SweepItem it = items[item_id];
     const rsrc_t rv = make_rsrc(values, values_bytes), rx = make_rsrc(x, num_cols * (uint32_t)sizeof(T));
     const uint64_t lt = lanemask_lt();
@@ -265,8 +309,16 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
         for (int h = 0; h < 2; h++) {
             const uint64_t bm = h ? bm1 : bm0;
             const uint32_t vo = h ? vo1 : vo0, xb = h ? x1 : x0, tb = h ? tb1 : tb0;
-            // dense tiles are queued for the wave-wide pass
-            const bool dense = __popcll(bm) > kSparseMax;
+            // full tiles have their own queue: no bitmap, values at fixed places
+            const bool full = FULL && bm == ~0ull && (sizeof(T) >= 4 || (vo & 3u) == 0u);  // multi-dword loads want dword-aligned values
+            const uint64_t fm = __ballot(full);
+            const int fn = __popcll(fm);
+            if (full) {
+                const int s = __popcll(fm & lt);
+                f_off[s] = vo; f_xb[s] = xb; f_tb[s] = tb;
+            }
+            // other dense tiles are queued for the wave-wide pass
+            const bool dense = !full && __popcll(bm) > kSparseMax;
             const uint64_t dm = __ballot(dense);
             const int qn = __popcll(dm);
             if (dense) {
@@ -274,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
                 d_bmp[s] = bm; d_off[s] = vo; d_xb[s] = xb; d_tb[s] = tb;
             }
             // every sparse tile: its first kInlineSlots stored values right here (covers most tiles of a graph matrix entirely)
-            const uint64_t rest = peel_tile<T, A, kInlineSlots>(dense ? 0ull : bm, vo, xb, tile + tb, rv, rx);
+            const uint64_t rest = peel_tile<T, A, kInlineSlots>((dense || full) ? 0ull : bm, vo, xb, tile + tb, rv, rx);
             // tiles with more values wait in the leftover queue until 64 of them make a full wave
             const uint64_t lm = __ballot(rest != 0);
             if (rest) {
@@ -287,6 +339,28 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
                 n_left -= 64u;
                 const uint32_t s = n_left + (uint32_t)lane;
                 peel_tile<T, A, kSparseMax - kInlineSlots>(l_bmp[s], l_off[s], l_xb[s], tile + l_tb[s], rv, rx);
+            }
+            // full tiles: 16 lanes per tile, each lane four consecutive values of one tile row (one 16-byte load) against the
+            // matching four x entries; the two half-rows meet in one DPP add; four tiles per step, kFullTrip steps in flight
+            for (int q = 0; FULL && q < fn; q += 4 * kFullTrip) {
+                const int ts = lane >> 4, rr = (lane >> 1) & 7, hf = lane & 1;
+                A part[kFullTrip];
+#pragma unroll
+                for (int t = 0; t < kFullTrip; t++) {
+                    const int e = q + 4 * t + ts;
+                    const bool on = e < fn;
+                    const int ee = on ? e : 0;
+                    A a4[4], x4[4];
+                    Buf4<T>::ld(rv, on ? f_off[ee] + (uint32_t)((rr * 8 + hf * 4) * sizeof(T)) : kOob, a4);
+                    Buf4<T>::ld(rx, on ? f_xb[ee] + (uint32_t)(hf * 4 * sizeof(T)) : kOob, x4);
+                    part[t] = a4[0] * x4[0] + a4[1] * x4[1] + a4[2] * x4[2] + a4[3] * x4[3];
+                }
+#pragma unroll
+                for (int t = 0; t < kFullTrip; t++) {
+                    const int e = q + 4 * t + ts;
+                    const A other = __shfl_xor(part[t], 1, kWave);
+                    if (e < fn && hf == 0) lds_add(tile + f_tb[e] + rr, part[t] + other);
+                }
             }
             // dense tiles: the whole wave per tile, lane p owns tile position p (coalesced value loads), kDenseTrip tiles per trip
             for (int q = 0; q < qn; q += kDenseTrip) {
@@ -419,7 +493,8 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
         build_plan(A, st);
         const uint32_t n_items = (uint32_t)A->spmv_num_chunks;
         char *mem = (char *)A->spmv_chunks;
-        hipLaunchKernelGGL((spmv_sweep_kernel<T>), dim3((n_items + 3) / 4), dim3(kThreads), 0, st, (const SweepItem *)(mem + 64), n_items,
+        auto kern = A->spmv_full_tiles * 4 >= A->block_num ? spmv_sweep_kernel<T, true> : spmv_sweep_kernel<T, false>;
+        hipLaunchKernelGGL(kern, dim3((n_items + 3) / 4), dim3(kThreads), 0, st, (const SweepItem *)(mem + 64), n_items,
                            A->keys, A->bmps, A->offsets, (const T *)A->values, (const T *)v, (Ac *)u,
                            (Ac *)(mem + A->spmv_plan_off_carry), (uint32_t *)(mem + A->spmv_plan_off_cnt), (uint32_t)A->num_rows,
                            (uint32_t)A->num_cols, (uint32_t)((size_t)A->values_extent() * sizeof(T)));

@@ -154,7 +154,7 @@ def test_spmv_fixtures(oracle, bmsp, path):
     check_spmv(oracle, bmsp, coo.num_rows, coo.num_cols, coo.rows, coo.cols, coo.vals)  # includes empty rows / ragged edges
 
 
-@pytest.mark.parametrize("case", ["banded", "rmat", "ragged", "empty_rows", "wide", "hub", "one_block_rows", "gap"])
+@pytest.mark.parametrize("case", ["banded", "rmat", "ragged", "empty_rows", "wide", "hub", "one_block_rows", "gap", "full_tiles", "full_tiles_odd"])
 def test_spmv_synthetic(oracle, bmsp, case):
     from pybmsp import gen
     if case == "banded":
@@ -175,6 +175,16 @@ def test_spmv_synthetic(oracle, bmsp, case):
         r, c, v = np.concatenate([r1, r2 + 1000]), np.concatenate([c1, c2]), np.concatenate([v1, v2])
         _, idx = np.unique(r.astype(np.int64) * nc + c, return_index=True)
         r, c, v = r[idx], c[idx], v[idx]
+    elif case == "full_tiles":
+        nr, nc, r, c, v = gen.banded(3001, 24)  # 5 of 7 tiles per block-row hold all 64 values: the 16-byte full-tile pass
+    elif case == "full_tiles_odd":
+        # full tiles behind tiles with odd value counts: fp16 values of a full tile start 2-byte aligned (takes the general path)
+        _, _, r1, c1, v1 = gen.banded(1601, 24)
+        r2 = np.arange(0, 1601, 3); c2 = (r2 + 200) % 1601; v2 = np.linspace(0.25, 1.0, r2.size)
+        nr = nc = 1601
+        r, c, v = np.concatenate([r1, r2]), np.concatenate([c1, c2]), np.concatenate([v1, v2])
+        _, idx = np.unique(r.astype(np.int64) * nc + c, return_index=True)
+        r, c, v = r[idx], c[idx], v[idx]
     elif case == "one_block_rows":
         n = 3000  # one tile per block-row: items are bounded by the 64-row window, not by the tile budget
         r = np.arange(n); c = (np.arange(n) * 7) % n; v = np.linspace(-1, 1, n)
@@ -185,6 +195,41 @@ def test_spmv_synthetic(oracle, bmsp, case):
         r = np.array([0, 3, 9, 99990, 99999]); c = np.array([5, 99999, 0, 17, 99999]); v = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
     check_spmv(oracle, bmsp, nr, nc, r, c, v)
     check_spmv(oracle, bmsp, nr, nc, r, c, v, "ones")
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("case", ["rmat", "full_tiles", "full_tiles_odd", "hub"])
+def test_spmv_half_and_double(bmsp, dtype, case):
+    """bmSpMatrix<half> / <double> sweeps (instantiated at src/bmSpMatrix.cu:435-437): fp16 values and x with fp32 accumulation,
+    fp64 throughout; against scipy in float64 on the rounded inputs."""
+    import scipy.sparse as sp
+    from pybmsp import gen
+    if case == "rmat":
+        n, _, r, c, v = gen.rmat(11, 8)
+    elif case == "full_tiles":
+        n, _, r, c, v = gen.banded(3001, 24)
+    elif case == "full_tiles_odd":
+        _, _, r1, c1, v1 = gen.banded(1601, 24)
+        r2 = np.arange(0, 1601, 3); c2 = (r2 + 200) % 1601; v2 = np.linspace(0.25, 1.0, r2.size)
+        n = 1601
+        r, c, v = np.concatenate([r1, r2]), np.concatenate([c1, c2]), np.concatenate([v1, v2])
+        _, idx = np.unique(r.astype(np.int64) * n + c, return_index=True)
+        r, c, v = r[idx], c[idx], v[idx]
+    else:
+        n, _, r, c, v = gen.random_coo(16, 40000, 50000, seed=6)
+        n = 40000
+    np_in = bmsp.NP_DTYPE[dtype]
+    vq = np.asarray(v, np.float64).astype(np_in)
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=dtype)
+    x = gen.spmv_x(n, "cusp").astype(np_in)
+    S = sp.coo_matrix((vq.astype(np.float64), (r, c)), shape=(n, n)).tocsr()
+    want = S @ x.astype(np.float64)
+    mag = abs(S) @ np.abs(x.astype(np.float64))
+    tol = 1e-5 if dtype == 1 else 1e-13  # fp32 accumulation of exact fp16 products / fp64
+    for variant in (0, 1):
+        y = bmsp.DeviceArray(n, bmsp.OUT_DTYPE[dtype])
+        bmsp.check(bmsp.lib().bmsp_spmv(A.h, bmsp.DeviceArray.from_host(x).ptr, y.ptr, variant, None))
+        assert np.all(np.abs(y.to_host().astype(np.float64) - want) <= tol * mag + 1e-30)
 
 
 def test_spmv_linearity_large(bmsp):
