@@ -311,7 +311,8 @@ def bench_spmv_sharded(B, np, torch, dist, rank, world, A, x, y_whole):
     scaling; the headline `value` above is the weak-scaling replica rate)."""
     from pybmsp import shard
     bounds = shard.spmv_row_bounds(A, world)
-    full, st = shard.spmv_sharded(A, x, rank, world, dist, torch, bounds)  # warm-up, and the check below
+    view = A.row_panel(int(bounds[rank]), int(bounds[rank + 1]))  # built once: keeps its sweep plan across products
+    full, st = shard.spmv_sharded(A, x, rank, world, dist, torch, bounds, view)  # warm-up, and the check below
     ref = torch.empty_like(full)
     B.check(B.lib().bmsp_memcpy_d2d(ref.data_ptr(), y_whole.ptr, full.numel() * full.element_size()))
     same = bool(torch.equal(full, ref))
@@ -320,7 +321,7 @@ def bench_spmv_sharded(B, np, torch, dist, rank, world, A, x, y_whole):
     t0 = time.perf_counter()
     gather_ms = 0.0
     for _ in range(reps):
-        full, st = shard.spmv_sharded(A, x, rank, world, dist, torch, bounds)
+        full, st = shard.spmv_sharded(A, x, rank, world, dist, torch, bounds, view)
         gather_ms += st["gather_ms"]
     torch.cuda.synchronize(); dist.barrier()
     ms = (time.perf_counter() - t0) * 1e3 / reps

@@ -114,15 +114,17 @@ def spmv_row_bounds(A, parts):
     return balanced_bounds(np.diff(offsets[rowptr]), parts)
 
 
-def spmv_sharded(A, x, rank, world, dist, torch, bounds=None):
+def spmv_sharded(A, x, rank, world, dist, torch, bounds=None, view=None):
     """y = A x with A cut into block-row panels (x replicated): every rank sweeps its panel, the y slices are exchanged with one
-    padded all-gather, and every rank returns the whole y as a CUDA tensor.  No collective touches the sweep itself."""
+    padded all-gather, and every rank returns the whole y as a CUDA tensor.  No collective touches the sweep itself.
+    Pass the rank's `view` (A.row_panel(bounds[rank], bounds[rank + 1])) to reuse its cached sweep plan across calls."""
     import pybmsp as B
     info = A.info()
     if bounds is None:
         bounds = spmv_row_bounds(A, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    view = A.row_panel(lo, hi)
+    if view is None:
+        view = A.row_panel(lo, hi)
     y = B.spmv(view, x)  # rows outside the panel come out as zeros
     r0, r1 = min(lo * 8, info["num_rows"]), min(hi * 8, info["num_rows"])
     tdt = torch.float64 if info["dtype"] == B.F64 else torch.float32
