@@ -312,19 +312,6 @@ struct EmitRunStarts {
         if (is_head) segs[ex] = (int)i;  // RunHead's value for this element
     }
 };
-struct MaskLow {
-    uint64_t *keys;
-    const uint64_t *src;
-    uint64_t mask;
-    __device__ void operator()(uint64_t i) const { keys[i] = src[i] & mask; }
-};
-struct RestoreHigh {
-    uint64_t *keys;        // sorted low parts
-    const uint64_t *orig;  // original keys (any element of the same segment has the right high part)
-    uint64_t mask;
-    __device__ void operator()(uint64_t i) const { keys[i] = (orig[i] & ~mask) | keys[i]; }
-};
-
 }  // namespace
 
 void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const int *d_segs, int64_t num_segs, hipStream_t st)

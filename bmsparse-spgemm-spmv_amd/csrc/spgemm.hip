@@ -153,14 +153,6 @@ struct KeyHead {
         return (t == 0 || sk[t] != sk[t - 1]) ? 1u : 0u;
     }
 };
-struct TotalOut32 {
-    uint64_t n;
-    uint32_t *total;
-    __device__ void operator()(uint64_t i, uint32_t ex) const
-    {
-        if (i == n) *total = ex;
-    }
-};
 struct EmitCBlocks {
     const uint64_t *sk;
     uint64_t n;
