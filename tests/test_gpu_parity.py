@@ -325,7 +325,7 @@ def test_spgemm_fixtures_square(oracle, bmsp, path, dtype, tc):
         check_spgemm(oracle, bmsp, t, t, dtype, mode, tc, exact_expected=True)
 
 
-@pytest.mark.parametrize("case", ["rect", "banded", "rmat", "empty_rows", "filtered", "single_block", "wide", "long_segments", "hub_c_blocks"])
+@pytest.mark.parametrize("case", ["rect", "banded", "rmat", "empty_rows", "filtered", "single_block", "wide", "long_segments", "hub_c_blocks", "hub_row"])
 @pytest.mark.parametrize("dtype,tc", [(0, 5), (1, 5), (1, 4), (2, 5)])
 def test_spgemm_synthetic(oracle, bmsp, case, dtype, tc):
     from pybmsp import gen
@@ -359,6 +359,15 @@ def test_spgemm_synthetic(oracle, bmsp, case, dtype, tc):
         rc, first = np.unique(np.concatenate([ra.ravel(), r2]) * 2400 + np.concatenate([ca.ravel(), c2]), return_index=True)
         A = (64, 2400, rc // 2400, rc % 2400, np.concatenate([np.ones(ra.size), v2])[first])
         B = (2400, 16, rb.ravel(), cb.ravel(), np.ones(rb.size) * 0.5)
+    elif case == "hub_row":
+        # one block-row of A with 5600 surviving tasks (> 4096: the segmented path has to hand over to the global sort, which
+        # it only learns at its next read-back) next to ordinary rows
+        ra = np.zeros(5600, dtype=np.int64); ca = np.arange(5600)
+        _, _, r2, c2, v2 = gen.random_coo(40, 5600, 900, seed=12, lo=0, hi=1)
+        rc, first = np.unique(np.concatenate([ra, r2 + 8]) * 5600 + np.concatenate([ca, c2]), return_index=True)
+        A = (48, 5600, rc // 5600, rc % 5600, np.concatenate([np.ones(5600), v2])[first])
+        rb, cb = np.meshgrid(np.arange(5600), np.arange(0, 64, 8), indexing="ij")
+        B = (5600, 64, rb.ravel(), cb.ravel(), np.full(rb.size, 0.5))
     elif case == "filtered":
         # A uses only even k, B only odd k inside every tile: every candidate pair dies in the bitmap filter
         n = 256
