@@ -66,7 +66,9 @@ __device__ __forceinline__ uint32_t upper_bound_u64(const uint64_t *p, uint32_t 
     return lo;
 }
 
-template <bool WRITE>
+// ITEMS candidates per thread: 16 (4096 per workgroup) on large products; 2 on small ones, where a tile's 16 dependent rounds
+// would run on a handful of workgroups (the banded bench case: 28 workgroups x 31 us -> 223 x 8 us)
+template <bool WRITE, int ITEMS>
 __global__ __launch_bounds__(kThreads) void expand_filter_kernel(ExpandArgs g, uint32_t *__restrict__ tile_counts,
                                                                  const uint32_t *__restrict__ tile_base, uint64_t *__restrict__ out_keys,
                                                                  uint64_t *__restrict__ out_tasks)
@@ -74,8 +76,9 @@ __global__ __launch_bounds__(kThreads) void expand_filter_kernel(ExpandArgs g, u
     __shared__ uint32_t rel[kSpanMax + 1];
     __shared__ uint32_t range[2];
     __shared__ uint32_t lds4[4];
-    const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
-    const uint64_t t1 = (t0 + (uint64_t)kTile < g.total) ? t0 + (uint64_t)kTile : g.total;
+    constexpr uint32_t kTileE = (uint32_t)ITEMS * kThreads;
+    const uint64_t t0 = (uint64_t)blockIdx.x * kTileE;
+    const uint64_t t1 = (t0 + (uint64_t)kTileE < g.total) ? t0 + (uint64_t)kTileE : g.total;
     if (threadIdx.x == 0) range[0] = upper_bound_u64(g.first_pos, 0, (uint32_t)g.n_a + 1, t0) - 1;
     if (threadIdx.x == 64) range[1] = upper_bound_u64(g.first_pos, 0, (uint32_t)g.n_a + 1, t1 - 1) - 1;
     __syncthreads();
@@ -85,13 +88,13 @@ __global__ __launch_bounds__(kThreads) void expand_filter_kernel(ExpandArgs g, u
     if (staged) {
         for (uint32_t k = threadIdx.x; k <= span; k += kThreads) {
             uint64_t fp = g.first_pos[a_lo + k];
-            rel[k] = fp <= t0 ? 0u : (fp - t0 < (uint64_t)kTile ? (uint32_t)(fp - t0) : (uint32_t)kTile);
+            rel[k] = fp <= t0 ? 0u : (fp - t0 < (uint64_t)kTileE ? (uint32_t)(fp - t0) : kTileE);
         }
     }
     __syncthreads();
     uint32_t carry = WRITE ? tile_base[blockIdx.x] : 0u;
     uint32_t kept_total = 0;
-    for (int k = 0; k < kItems; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         uint64_t t = t0 + (uint64_t)k * kThreads + threadIdx.x;
         bool keep = false;
         uint32_t a = 0, b = 0;
@@ -858,14 +861,20 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     // T_3 + T_4: expansion fused with the bitmap filter
     const int jbits = std::max(1, ceil_log2_u64((uint64_t)B->num_block_cols()));
     const int ibits = std::max(1, ceil_log2_u64((uint64_t)A->num_block_rows()));
-    const uint32_t tiles = (uint32_t)((total + kTile - 1) / kTile);
+    const bool small_product = total <= (2u << 20);
+    const uint32_t tile_e = small_product ? 2u * kThreads : (uint32_t)kTile;
+    const uint32_t tiles = (uint32_t)((total + tile_e - 1) / tile_e);
     ExpandArgs ea{first_pos.p, A->keys, A->bmps, B->keys, B->bmps, B->rowptr, n_a, total, jbits};
     DevBuf<uint32_t> tile_counts((size_t)tiles + 1);
     uint64_t n_tasks = 0;
     DevBuf<uint64_t> k0, k1, v0, v1;
     if (total) {
-        hipLaunchKernelGGL((expand_filter_kernel<false>), dim3(tiles), dim3(kThreads), 0, st, ea, tile_counts.p, (const uint32_t *)nullptr,
-                           (uint64_t *)nullptr, (uint64_t *)nullptr);
+        if (small_product)
+            hipLaunchKernelGGL((expand_filter_kernel<false, 2>), dim3(tiles), dim3(kThreads), 0, st, ea, tile_counts.p, (const uint32_t *)nullptr,
+                               (uint64_t *)nullptr, (uint64_t *)nullptr);
+        else
+            hipLaunchKernelGGL((expand_filter_kernel<false, kItems>), dim3(tiles), dim3(kThreads), 0, st, ea, tile_counts.p, (const uint32_t *)nullptr,
+                               (uint64_t *)nullptr, (uint64_t *)nullptr);
         BMSP_CHECK_LAUNCH();
         DevBuf<uint32_t> tile_base((size_t)tiles + 1);
         HostScalar<uint32_t> n_tasks_h;
@@ -873,8 +882,12 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         n_tasks = n_tasks_h.wait(st);
         tm.mark(3);
         k0.alloc(n_tasks); k1.alloc(n_tasks); v0.alloc(n_tasks); v1.alloc(n_tasks);
-        hipLaunchKernelGGL((expand_filter_kernel<true>), dim3(tiles), dim3(kThreads), 0, st, ea, (uint32_t *)nullptr,
-                           (const uint32_t *)tile_base.p, k0.p, v0.p);
+        if (small_product)
+            hipLaunchKernelGGL((expand_filter_kernel<true, 2>), dim3(tiles), dim3(kThreads), 0, st, ea, (uint32_t *)nullptr, (const uint32_t *)tile_base.p, k0.p,
+                               v0.p);
+        else
+            hipLaunchKernelGGL((expand_filter_kernel<true, kItems>), dim3(tiles), dim3(kThreads), 0, st, ea, (uint32_t *)nullptr, (const uint32_t *)tile_base.p,
+                               k0.p, v0.p);
         BMSP_CHECK_LAUNCH();
         tm.mark(4);
     }
