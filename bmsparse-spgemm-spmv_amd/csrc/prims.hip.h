@@ -61,14 +61,17 @@ __device__ __forceinline__ T block_exclusive_sum(T v, T *lds, T &total)
 // exclusive scan:  out(i, sum_{j<i} in(j))  for i in [0, n)
 // In : T operator()(uint64_t i) const ;  Out : void operator()(uint64_t i, T exclusive) const
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename In>
+// ITEMS elements per thread: kItems (4096 per tile) on long arrays, kItemsSmall on short ones so that they still spread
+// over many workgroups and a tile is one round of loads
+constexpr int kItemsSmall = 4;
+template <typename T, typename In, int ITEMS>
 __global__ __launch_bounds__(kThreads) void scan_tile_sums_kernel(In in, uint64_t n, T *tile_sums)
 {
     __shared__ T lds[4];
-    uint64_t base = (uint64_t)blockIdx.x * kTile;
+    uint64_t base = (uint64_t)blockIdx.x * (ITEMS * kThreads);
     T local = 0;
 #pragma unroll 4
-    for (int k = 0; k < kItems; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
         if (i < n) local += in(i);
     }
@@ -90,22 +93,23 @@ __device__ __forceinline__ void scan_emit(const Out &o, uint64_t i, T ex, T, lon
     o(i, ex);
 }
 
-template <typename T, typename In, typename Out>
+template <typename T, typename In, typename Out, int ITEMS>
 __global__ __launch_bounds__(kThreads) void scan_tile_down_kernel(In in, Out out, uint64_t n, const T *tile_excl,
                                                                   uint64_t tiles_per_block)
 {
+    constexpr uint64_t kTileS = (uint64_t)ITEMS * kThreads;
     __shared__ T lds[4];
     // tile_excl == nullptr: a single workgroup walks all tiles with a running carry
     uint64_t first_tile = (uint64_t)blockIdx.x * tiles_per_block;
     T carry = tile_excl ? tile_excl[first_tile] : T(0);
     for (uint64_t t = 0; t < tiles_per_block; t++) {
-        uint64_t base = (first_tile + t) * kTile;
+        uint64_t base = (first_tile + t) * kTileS;
         if (base >= n) break;
         // inputs are fetched kBatchLoads at a time (independent loads, one round trip per batch) before their block scans:
         // enough to hide the latency when a single workgroup walks a short array, without the register cost of a whole tile
         constexpr int kBatchLoads = 4;
 #pragma unroll
-        for (int k0 = 0; k0 < kItems; k0 += kBatchLoads) {
+        for (int k0 = 0; k0 < ITEMS; k0 += kBatchLoads) {
             T v[kBatchLoads];
 #pragma unroll
             for (int k = 0; k < kBatchLoads; k++) {
@@ -135,22 +139,33 @@ struct PtrOut {
     __device__ void operator()(uint64_t i, T v) const { p[i] = v; }
 };
 
+template <typename T, typename In, typename Out, int ITEMS>
+void device_exclusive_scan_impl(In in, Out out, uint64_t n, hipStream_t st);
+
 template <typename T, typename In, typename Out>
 void device_exclusive_scan(In in, Out out, uint64_t n, hipStream_t st)
 {
     if (n == 0) return;
-    uint64_t tiles = (n + kTile - 1) / kTile;
-    if (tiles <= 2) {  // a lone workgroup walks short arrays; beyond that three parallel launches beat its serial latency chain
-        hipLaunchKernelGGL((scan_tile_down_kernel<T, In, Out>), dim3(1), dim3(kThreads), 0, st, in, out, n,
+    if (n <= (1u << 20)) device_exclusive_scan_impl<T, In, Out, kItemsSmall>(in, out, n, st);
+    else device_exclusive_scan_impl<T, In, Out, kItems>(in, out, n, st);
+}
+
+template <typename T, typename In, typename Out, int ITEMS>
+void device_exclusive_scan_impl(In in, Out out, uint64_t n, hipStream_t st)
+{
+    constexpr uint64_t kTileS = (uint64_t)ITEMS * kThreads;
+    uint64_t tiles = (n + kTileS - 1) / kTileS;
+    if (n <= 8192) {  // a lone workgroup walks short arrays; beyond that three parallel launches beat its serial latency chain
+        hipLaunchKernelGGL((scan_tile_down_kernel<T, In, Out, ITEMS>), dim3(1), dim3(kThreads), 0, st, in, out, n,
                            (const T *)nullptr, tiles);
         BMSP_CHECK_LAUNCH();
         return;
     }
     DevBuf<T> sums(tiles);
-    hipLaunchKernelGGL((scan_tile_sums_kernel<T, In>), dim3((unsigned)tiles), dim3(kThreads), 0, st, in, n, sums.p);
+    hipLaunchKernelGGL((scan_tile_sums_kernel<T, In, ITEMS>), dim3((unsigned)tiles), dim3(kThreads), 0, st, in, n, sums.p);
     BMSP_CHECK_LAUNCH();
     device_exclusive_scan<T>(PtrIn<T>{sums.p}, PtrOut<T>{sums.p}, tiles, st);
-    hipLaunchKernelGGL((scan_tile_down_kernel<T, In, Out>), dim3((unsigned)tiles), dim3(kThreads), 0, st, in, out, n,
+    hipLaunchKernelGGL((scan_tile_down_kernel<T, In, Out, ITEMS>), dim3((unsigned)tiles), dim3(kThreads), 0, st, in, out, n,
                        (const T *)sums.p, (uint64_t)1);
     BMSP_CHECK_LAUNCH();
     // sums is returned to the pool here; the pool never hands memory back to the driver while kernels
