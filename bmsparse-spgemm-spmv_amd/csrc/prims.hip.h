@@ -180,17 +180,18 @@ void device_exclusive_scan_impl(In in, Out out, uint64_t n, hipStream_t st)
 constexpr int kRadixMaxBits = 9;
 constexpr int kRadixMaxBins = 1 << kRadixMaxBits;  // two bins per thread
 
-static __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint32_t n, int shift, int bits,
-                                                              uint32_t *__restrict__ hist, uint32_t num_tiles)
+template <int ITEMS>
+__global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint32_t n, int shift, int bits,
+                                                       uint32_t *__restrict__ hist, uint32_t num_tiles)
 {
     __shared__ uint32_t h[kRadixMaxBins];
     const uint32_t bins = 1u << bits, mask = bins - 1u;
     h[threadIdx.x] = 0;
     h[threadIdx.x + kThreads] = 0;
     __syncthreads();
-    uint64_t base = (uint64_t)blockIdx.x * kTile;
+    uint64_t base = (uint64_t)blockIdx.x * (ITEMS * kThreads);
 #pragma unroll 4
-    for (int k = 0; k < kItems; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
     }
@@ -205,7 +206,7 @@ static __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint6
 // The tile is then reordered IN LDS by digit before it leaves: consecutive threads write consecutive destinations, so a
 // digit's run inside the tile (8+ elements on average) goes out as whole 64-byte segments instead of one scattered 8-byte
 // store per key.  Keys and payloads take turns in the same 32 KB staging buffer.
-template <typename P>
+template <typename P, int ITEMS>
 __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t *__restrict__ kin, const P *__restrict__ pin,
                                                                  uint64_t *__restrict__ kout, P *__restrict__ pout, uint32_t n,
                                                                  int shift, int bits, const uint32_t *__restrict__ hist_scanned,
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
     __shared__ uint32_t cnt[4][kRadixMaxBins];
     __shared__ uint32_t local_base[4][kRadixMaxBins];  // first staging slot of (wave, digit)
     __shared__ uint32_t out_shift[kRadixMaxBins];      // global destination of a digit's run minus its first staging slot
-    __shared__ uint64_t stage[kTile];
+    constexpr uint32_t kTileR = (uint32_t)ITEMS * kThreads;  // keys per workgroup: each wave owns ITEMS * 64 consecutive ones
+    __shared__ uint64_t stage[kTileR];
     __shared__ uint32_t scan_lds[4];
     const uint32_t bins = 1u << bits, mask = bins - 1u;
     for (int w = 0; w < 4; w++) {
@@ -223,14 +225,14 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
     }
     __syncthreads();
     const int w = wave_id(), lane = lane_id();
-    const uint64_t tile0 = (uint64_t)blockIdx.x * kTile;
-    const uint64_t slice = tile0 + (uint64_t)w * (kTile / 4);
-    const uint32_t tile_n = (uint32_t)min((uint64_t)kTile, (uint64_t)n - tile0);
-    uint64_t key[kItems];
-    uint32_t pos[kItems];  // rank inside (wave, digit), then the staging slot
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kTileR;
+    const uint64_t slice = tile0 + (uint64_t)w * (kTileR / 4);
+    const uint32_t tile_n = (uint32_t)min((uint64_t)kTileR, (uint64_t)n - tile0);
+    uint64_t key[ITEMS];
+    uint32_t pos[ITEMS];  // rank inside (wave, digit), then the staging slot
     const uint64_t lt = lanemask_lt();
 #pragma unroll
-    for (int r = 0; r < kItems; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         uint64_t i = slice + (uint64_t)r * kWave + lane;
         bool valid = i < n;
         key[r] = valid ? kin[i] : ~0ull;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
     __syncthreads();
     // keys through the staging buffer
 #pragma unroll
-    for (int r = 0; r < kItems; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         uint64_t i = slice + (uint64_t)r * kWave + lane;
         if (i < n) {
             uint32_t d = (uint32_t)(key[r] >> shift) & mask;
@@ -285,9 +287,9 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
         }
     }
     __syncthreads();
-    uint32_t dst[kItems];
+    uint32_t dst[ITEMS];
 #pragma unroll
-    for (int k = 0; k < kItems; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         const uint32_t i = (uint32_t)k * kThreads + threadIdx.x;
         dst[k] = 0;
         if (i < tile_n) {
@@ -299,20 +301,20 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t 
     __syncthreads();
     // payloads through the same buffer
     P *pstage = reinterpret_cast<P *>(stage);
-    P pv[kItems];
+    P pv[ITEMS];
 #pragma unroll
-    for (int r = 0; r < kItems; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         uint64_t i = slice + (uint64_t)r * kWave + lane;
         if (i < n) pv[r] = pin[i];
     }
 #pragma unroll
-    for (int r = 0; r < kItems; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         uint64_t i = slice + (uint64_t)r * kWave + lane;
         if (i < n) pstage[pos[r]] = pv[r];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kItems; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         const uint32_t i = (uint32_t)k * kThreads + threadIdx.x;
         if (i < tile_n) pout[dst[k]] = pstage[i];
     }
@@ -351,6 +353,9 @@ struct PingPong {
 
 // Sorts by key bits [begin_bit, end_bit).  On return keys.cur / vals.cur hold the sorted data (they may be the
 // buffers that were passed as .alt).
+template <typename P, int ITEMS>
+void device_radix_sort_pairs_impl(PingPong<uint64_t> &keys, PingPong<P> &vals, uint32_t n, int begin_bit, int end_bit, hipStream_t st);
+
 template <typename P>
 void device_radix_sort_pairs(PingPong<uint64_t> &keys, PingPong<P> &vals, uint64_t n64, int begin_bit, int end_bit,
                              hipStream_t st)
@@ -358,18 +363,26 @@ void device_radix_sort_pairs(PingPong<uint64_t> &keys, PingPong<P> &vals, uint64
     if (n64 == 0 || end_bit <= begin_bit) return;
     if (n64 >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "radix sort: %llu elements exceed the 32-bit position range",
                                   (unsigned long long)n64);
-    uint32_t n = (uint32_t)n64;
-    uint32_t tiles = (uint32_t)((n64 + kTile - 1) / kTile);
+    // short arrays: 1024-key tiles keep every pass spread over many workgroups
+    if (n64 <= (1u << 20)) device_radix_sort_pairs_impl<P, kItemsSmall>(keys, vals, (uint32_t)n64, begin_bit, end_bit, st);
+    else device_radix_sort_pairs_impl<P, kItems>(keys, vals, (uint32_t)n64, begin_bit, end_bit, st);
+}
+
+template <typename P, int ITEMS>
+void device_radix_sort_pairs_impl(PingPong<uint64_t> &keys, PingPong<P> &vals, uint32_t n, int begin_bit, int end_bit, hipStream_t st)
+{
+    constexpr uint32_t kTileR = (uint32_t)ITEMS * kThreads;
+    uint32_t tiles = (uint32_t)(((uint64_t)n + kTileR - 1) / kTileR);
     const int total_bits = end_bit - begin_bit;
     const int passes = (total_bits + kRadixMaxBits - 1) / kRadixMaxBits;
     const int width = (total_bits + passes - 1) / passes;
     DevBuf<uint32_t> hist((size_t)(1u << width) * tiles);
     for (int shift = begin_bit; shift < end_bit; shift += width) {
         const int bits = std::min(width, end_bit - shift);
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(kThreads), 0, st, keys.cur, n, shift, bits, hist.p, tiles);
+        hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(tiles), dim3(kThreads), 0, st, keys.cur, n, shift, bits, hist.p, tiles);
         BMSP_CHECK_LAUNCH();
         device_exclusive_scan<uint32_t>(PtrIn<uint32_t>{hist.p}, PtrOut<uint32_t>{hist.p}, (uint64_t)(1u << bits) * tiles, st);
-        hipLaunchKernelGGL((radix_scatter_kernel<P>), dim3(tiles), dim3(kThreads), 0, st, keys.cur, vals.cur, keys.alt,
+        hipLaunchKernelGGL((radix_scatter_kernel<P, ITEMS>), dim3(tiles), dim3(kThreads), 0, st, keys.cur, vals.cur, keys.alt,
                            vals.alt, n, shift, bits, hist.p, tiles);
         BMSP_CHECK_LAUNCH();
         keys.flip();
