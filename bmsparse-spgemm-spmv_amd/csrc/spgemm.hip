@@ -224,6 +224,10 @@ __global__ __launch_bounds__(kThreads) void c_bitmaps_kernel(const uint64_t *__r
     }
 }
 
+struct ZeroU64 {
+    uint64_t *p;
+    __device__ void operator()(uint64_t i) const { p[i] = 0ull; }
+};
 struct PopcIn {
     const uint64_t *bmps;
     uint64_t n;
@@ -942,7 +946,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     // T_9: C bitmaps, value offsets, nnz
     uint64_t c_nnz = 0;
     if (c_size) {
-        BMSP_HIP(hipMemsetAsync(C->bmps, 0, 8 * (size_t)c_size, st));
+        device_for_each(ZeroU64{C->bmps}, (uint64_t)c_size, st);  // one launch (hipMemsetAsync splits into two fill kernels)
         hipLaunchKernelGGL(c_bitmaps_kernel, dim3((uint32_t)((n_tasks + 255) / 256)), dim3(kThreads), 0, st, kk.cur, vv.cur, (uint32_t)n_tasks, c_of_wave.p,
                            A->bmps, B->bmps, (unsigned long long *)C->bmps);
         BMSP_CHECK_LAUNCH();
