@@ -232,6 +232,30 @@ def test_spmv_half_and_double(bmsp, dtype, case):
         assert np.all(np.abs(y.to_host().astype(np.float64) - want) <= tol * mag + 1e-30)
 
 
+def test_spmv_bench_size_properties(bmsp):
+    """the SpMV bench workload at its full size (R-MAT 2^20 x 2 + I, the webbase-1M stand-in): A*1 equals the host row sums, two
+    sweeps are bit-identical (arrival counters reset, fixed fold order of hub rows), the block-row variants agree within tolerance."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(20, 2.0, seed=1)
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    v32 = np.asarray(v, np.float32).astype(np.float64)
+    rowsum = np.bincount(r, weights=v32, minlength=n)
+    absrow = np.bincount(r, weights=np.abs(v32), minlength=n)
+    ones = bmsp.DeviceArray.from_host(np.ones(n, np.float32))
+    first = None
+    for variant in (0, 0, 1):
+        du = bmsp.DeviceArray(n, np.float32)
+        assert bmsp.lib().bmsp_memset(du.ptr, 0xFF, n * 4) == 0
+        bmsp.check(bmsp.lib().bmsp_spmv(A.h, ones.ptr, du.ptr, variant, None))
+        y = du.to_host()
+        assert np.all(np.abs(y - rowsum) <= 1e-5 * absrow + 1e-6)
+        if variant == 0:
+            if first is None:
+                first = y
+            else:
+                np.testing.assert_array_equal(first.view(np.uint32), y.view(np.uint32))
+
+
 def test_spmv_linearity_large(bmsp):
     """size-independent property at a BASELINE-scale input (webbase-1M-like R-MAT): A(x+y) = Ax + Ay, and
     A*1 equals the row sums computed on the host."""
@@ -465,6 +489,45 @@ def test_spgemm_properties_large(bmsp):
         order = np.argsort(key_ref)
         np.testing.assert_array_equal(rr.astype(np.int64) * n + cc, key_ref[order])
         np.testing.assert_allclose(vv, ref.data[order], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", ["2cubes_sphere_like", "cage12_like"])
+def test_spgemm_bench_size_properties(bmsp, case):
+    """the two SpGEMM bench workloads at their full BASELINE.json sizes, through size-independent properties: the three sort
+    modes give bit-identical C (V15 numerics); C's pattern is scipy's pattern product; C*1 == A*(A*1) through the SpMV; the fp16
+    MFMA product agrees with the fp32 one within the stated fp16 tolerance."""
+    import scipy.sparse as sp
+    from pybmsp import gen
+    n, _, r, c, v = gen.banded(101492, 8) if case == "2cubes_sphere_like" else gen.cage_like(130228, 15.6)
+    v = np.round(np.asarray(v) * 64) / 64          # exactly representable in fp16 and fp32
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    At = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True)
+    ref, st0 = bmsp.spgemm(A, At, mode=0, tc_version=5)
+    ref_arrays = ref.host_arrays()
+    for mode in (1, 2):
+        Cm, st = bmsp.spgemm(A, At, mode=mode, tc_version=5)
+        assert (st["task_list_size"], st["surviving_tasks"], st["c_blocks"], st["c_nnz"]) == \
+               (st0["task_list_size"], st0["surviving_tasks"], st0["c_blocks"], st0["c_nnz"])
+        for x, y in zip(Cm.host_arrays(), ref_arrays):
+            np.testing.assert_array_equal(x, y)
+        del Cm
+    S = sp.coo_matrix((np.ones(r.size), (r, c)), shape=(n, n)).tocsr()
+    assert st0["c_nnz"] == (S @ S).nnz
+    ones = bmsp.DeviceArray.from_host(np.ones(n, np.float32))
+    a1 = bmsp.spmv(A, ones)
+    y_chain = bmsp.spmv(A, a1).to_host().astype(np.float64)
+    y_prod = bmsp.spmv(ref, ones).to_host().astype(np.float64)
+    Sabs = sp.coo_matrix((np.abs(v), (r, c)), shape=(n, n)).tocsr()
+    mag = Sabs @ (Sabs @ np.ones(n))
+    assert np.all(np.abs(y_chain - y_prod) <= 1e-5 * mag + 1e-6)
+    # fp16 inputs, matrix-core block-MAC (exact products, fp32 accumulation in hardware order)
+    Ah = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=bmsp.F16)
+    Aht = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=bmsp.F16)
+    Ch, sth = bmsp.spgemm(Ah, Aht, mode=0, tc_version=4)
+    kh, bh, oh, vh = Ch.host_arrays()
+    np.testing.assert_array_equal(kh, ref_arrays[0]); np.testing.assert_array_equal(bh, ref_arrays[1]); np.testing.assert_array_equal(oh, ref_arrays[2])
+    y_h = bmsp.spmv(Ch, ones).to_host().astype(np.float64)
+    assert np.all(np.abs(y_h - y_prod) <= 2.0 ** -10 * mag + 1e-6)
 
 
 def _segsort_cuts(shape, rng, n):
