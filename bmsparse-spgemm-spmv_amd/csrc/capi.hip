@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -12,7 +13,9 @@
 
 namespace bmsp {
 const std::string &last_error();
-void partition_rows(bmsp_matrix_s *A, bmsp_matrix_s *B, int parts, int64_t *bounds, hipStream_t st);
+void partition_rows(bmsp_matrix_s *A, bmsp_matrix_s *B, int parts, int64_t *bounds, hipStream_t st, uint64_t *total_out = nullptr);
+void spgemm_paneled(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int tc_version, int verbose, hipStream_t st,
+                    bmsp_spgemm_stats *stats);
 bmsp_matrix_s *row_panel(bmsp_matrix_s *m, int64_t rb, int64_t re, hipStream_t st);
 bmsp_matrix_s *concat_panels(int num_rows, int num_cols, int parts, const int64_t *block_nums, const int64_t *nnzs,
                              uint64_t *const *d_keys, uint64_t *const *d_bmps, uint64_t *const *d_offsets, void *const *d_values,
@@ -453,7 +456,14 @@ int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, in
                 bmsp_spgemm_stats *stats)
 {
     BMSP_API_BEGIN
-    spgemm(A, B, C, mode, tc_version, verbose, as_stream(stream), stats);
+    try {
+        if (getenv("BMSP_SPGEMM_FORCE_PANELS")) fail(BMSP_ERR_LIMIT, "forced: candidate block pairs (test hook for the paneled path)");
+        spgemm(A, B, C, mode, tc_version, verbose, as_stream(stream), stats);
+    } catch (const Error &e) {
+        // more candidate block pairs than one task list can index: the same product, block-row panel after panel
+        if (e.status != BMSP_ERR_LIMIT || std::string(e.what()).find("candidate block pairs") == std::string::npos) throw;
+        spgemm_paneled(A, B, C, mode, tc_version, verbose, as_stream(stream), stats);
+    }
     BMSP_API_END
 }
 

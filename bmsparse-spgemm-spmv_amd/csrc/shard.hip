@@ -6,6 +6,8 @@
 // whole pipeline on its panel, and the C panels are concatenated after an allgatherv of the four arrays.
 #include "matrix.h"
 #include "prims.hip.h"
+#include <memory>
+#include <vector>
 #include <vector>
 
 namespace bmsp {
@@ -36,7 +38,7 @@ struct RebaseOffsets {
 };
 }  // namespace
 
-void partition_rows(bmsp_matrix_s *A, bmsp_matrix_s *B, int parts, int64_t *bounds, hipStream_t st)
+void partition_rows(bmsp_matrix_s *A, bmsp_matrix_s *B, int parts, int64_t *bounds, hipStream_t st, uint64_t *total_out)
 {
     if (parts < 1) fail(BMSP_ERR_INVALID, "parts must be >= 1");
     ensure_rowptr(A, st);
@@ -51,6 +53,7 @@ void partition_rows(bmsp_matrix_s *A, bmsp_matrix_s *B, int parts, int64_t *boun
     BMSP_HIP(hipMemcpyAsync(h.data(), cum.p, 8 * ((size_t)nbr + 1), hipMemcpyDeviceToHost, st));
     BMSP_HIP(hipStreamSynchronize(st));
     const uint64_t total = h[(size_t)nbr];
+    if (total_out) *total_out = total;
     bounds[0] = 0;
     int64_t r = 0;
     for (int p = 1; p < parts; p++) {
@@ -119,6 +122,47 @@ bmsp_matrix_s *concat_panels(int num_rows, int num_cols, int parts, const int64_
     BMSP_HIP(hipMemcpyAsync(m->offsets + nb, &term, 8, hipMemcpyHostToDevice, st));
     BMSP_HIP(hipStreamSynchronize(st));
     return m;
+}
+
+// One GPU, a product whose candidate block pairs exceed the 32-bit task range: the same row-panel decomposition the multi-GPU path
+// uses, run panel after panel on this device and concatenated -- the reference has no such limit to hit only because it runs out of
+// memory first (16-byte tasks, unfiltered list materialised).
+void spgemm_paneled(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, int tc_version, int verbose, hipStream_t st,
+                    bmsp_spgemm_stats *stats)
+{
+    uint64_t total = 0;
+    int64_t one[2];
+    partition_rows(A, B, 1, one, st, &total);
+    int parts = (int)(total / (1ull << 31)) + 2;
+    std::vector<int64_t> bounds;
+    std::vector<bmsp_matrix_s *> panels;
+    bmsp_spgemm_stats acc{};
+    auto cleanup = [&]() { for (bmsp_matrix_s *m : panels) free_matrix(m); panels.clear(); };
+    try {
+        bounds.resize((size_t)parts + 1);
+        partition_rows(A, B, parts, bounds.data(), st, nullptr);
+        for (int p = 0; p < parts; p++) {
+            std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> view(row_panel(A, bounds[(size_t)p], bounds[(size_t)p + 1], st), free_matrix);
+            bmsp_matrix_s *cp = nullptr;
+            bmsp_spgemm_stats ps{};
+            spgemm(view.get(), B, &cp, mode, tc_version, verbose, st, &ps);  // a single hub block-row beyond the range still fails here
+            panels.push_back(cp);
+            acc.task_list_size += ps.task_list_size; acc.bmp_reduction += ps.bmp_reduction; acc.surviving_tasks += ps.surviving_tasks;
+            acc.c_blocks += ps.c_blocks; acc.c_nnz += ps.c_nnz;
+            for (int i = 0; i < 10; i++) acc.t_us[i] += ps.t_us[i];
+            acc.sort_path = ps.sort_path; acc.mac_kernel = ps.mac_kernel;
+        }
+        std::vector<int64_t> bn, nz;
+        std::vector<uint64_t *> k, b, o;
+        std::vector<void *> v;
+        for (bmsp_matrix_s *m : panels) { bn.push_back(m->block_num); nz.push_back(m->nnz); k.push_back(m->keys); b.push_back(m->bmps); o.push_back(m->offsets); v.push_back(m->values); }
+        *Cout = concat_panels(A->num_rows, B->num_cols, parts, bn.data(), nz.data(), k.data(), b.data(), o.data(), v.data(), panels[0]->dtype, st);
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+    if (stats) *stats = acc;
 }
 
 }  // namespace bmsp

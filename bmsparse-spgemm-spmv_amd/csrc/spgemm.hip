@@ -860,7 +860,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     const uint64_t total = total_h.wait(st);
     tm.mark(2);
     S->task_list_size = (int64_t)total;
-    if (total >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "%llu candidate block pairs exceed the 32-bit task range; shard by row panel", (unsigned long long)total);
+    if (total >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "%llu candidate block pairs exceed the 32-bit task range of one task list", (unsigned long long)total);  // bmsp_spgemm retries in panels
 
     // T_3 + T_4: expansion fused with the bitmap filter
     const int jbits = std::max(1, ceil_log2_u64((uint64_t)B->num_block_cols()));

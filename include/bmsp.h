@@ -178,7 +178,9 @@ typedef struct {
  * switch (:1132-1155): 5 = vector-ALU kernel with the reference's V15 numerics (each product rounded to the
  * input type, fp32 accumulate); 1..4 = matrix-core (MFMA) kernel: exact products, fp32 accumulate.
  * verbose != 0 prints the reference's stage lines to stdout.  stats may be NULL.
- * Synchronous with respect to the host on return (the reference ends with cudaDeviceSynchronize, :1158). */
+ * Synchronous with respect to the host on return (the reference ends with cudaDeviceSynchronize, :1158).
+ * A product with 2^32 or more candidate block pairs (more than one task list can index) is run block-row panel after panel
+ * and concatenated; stats then hold the sums over the panels (stage lines are printed per panel). */
 int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, int verbose,
                 void *stream, bmsp_spgemm_stats *stats);
 

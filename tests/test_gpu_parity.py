@@ -711,6 +711,47 @@ def test_spmm_against_scipy(oracle, bmsp, dtype, k):
             np.testing.assert_array_equal(Ys[:, :k], Y)
 
 
+def test_spgemm_paneled_fallback(bmsp, monkeypatch):
+    """products whose candidate block pairs exceed the 32-bit task range run block-row panel after panel inside bmsp_spgemm;
+    forced here on a small product: identical C, summed stage counters."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(12, 6)
+    for dtype, tc in ((bmsp.F32, 5), (bmsp.F16, 4)):
+        A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=dtype)
+        Bt = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=dtype)
+        whole, st0 = bmsp.spgemm(A, Bt, tc_version=tc)
+        monkeypatch.setenv("BMSP_SPGEMM_FORCE_PANELS", "1")
+        try:
+            paneled, st1 = bmsp.spgemm(A, Bt, tc_version=tc)
+        finally:
+            monkeypatch.delenv("BMSP_SPGEMM_FORCE_PANELS")
+        for x, y in zip(paneled.host_arrays(), whole.host_arrays()):
+            np.testing.assert_array_equal(x, y)
+        for key in ("task_list_size", "bmp_reduction", "surviving_tasks", "c_blocks", "c_nnz"):
+            assert st1[key] == st0[key]
+
+
+def test_spgemm_beyond_32bit_candidates(bmsp):
+    """R-MAT scale 22, edge factor 2: 7.9 G candidate block pairs -- more than one task list can index; checked through
+    C*1 == A*(A*1) with the SpMV and through the candidate count of the fan-out."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(22, 2)
+    v = np.round(np.asarray(v) * 16) / 16
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=bmsp.F16)
+    At = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=bmsp.F16)
+    Cm, st = bmsp.spgemm(A, At, tc_version=4)
+    assert st["task_list_size"] >= 1 << 32 and st["surviving_tasks"] > 0 and st["c_blocks"] == Cm.block_num
+    A32 = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    ones = bmsp.DeviceArray.from_host(np.ones(n, np.float32))
+    a1 = bmsp.spmv(A32, ones)
+    y_chain = bmsp.spmv(A32, a1).to_host().astype(np.float64)
+    y_prod = bmsp.spmv(Cm, ones).to_host().astype(np.float64)
+    absv = np.abs(v)
+    rs = np.bincount(r, weights=absv, minlength=n)
+    mag = np.bincount(r, weights=absv * rs[c], minlength=n)
+    assert np.all(np.abs(y_chain - y_prod) <= 2.0 ** -10 * mag + 1e-4)
+
+
 def test_borrowed_arrays_multiply(oracle, bmsp):
     """bmsp_matrix_from_arrays with ownership 2 (caller keeps the arrays), every MAC kernel."""
     from pybmsp import gen
