@@ -457,11 +457,10 @@ int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, in
 {
     BMSP_API_BEGIN
     try {
-        if (getenv("BMSP_SPGEMM_FORCE_PANELS")) fail(BMSP_ERR_LIMIT, "forced: candidate block pairs (test hook for the paneled path)");
+        if (getenv("BMSP_SPGEMM_FORCE_PANELS")) throw TaskRangeExceeded(BMSP_ERR_LIMIT, "forced (test hook for the paneled path)");
         spgemm(A, B, C, mode, tc_version, verbose, as_stream(stream), stats);
-    } catch (const Error &e) {
+    } catch (const TaskRangeExceeded &) {
         // more candidate block pairs than one task list can index: the same product, block-row panel after panel
-        if (e.status != BMSP_ERR_LIMIT || std::string(e.what()).find("candidate block pairs") == std::string::npos) throw;
         spgemm_paneled(A, B, C, mode, tc_version, verbose, as_stream(stream), stats);
     }
     BMSP_API_END

@@ -18,6 +18,11 @@ struct Error : std::runtime_error {
     Error(int st, const std::string &msg) : std::runtime_error(msg), status(st) {}
 };
 
+// a product has more candidate block pairs than one task list indexes (32 bits): bmsp_spgemm answers by running it in panels
+struct TaskRangeExceeded : Error {
+    using Error::Error;
+};
+
 [[noreturn]] void fail(int status, const char *fmt, ...);
 void set_last_error(const std::string &msg);
 

@@ -15,6 +15,7 @@
 #include "matrix.h"
 #include "prims.hip.h"
 #include <memory>
+#include <string>
 
 namespace bmsp {
 namespace {
@@ -860,7 +861,8 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     const uint64_t total = total_h.wait(st);
     tm.mark(2);
     S->task_list_size = (int64_t)total;
-    if (total >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "%llu candidate block pairs exceed the 32-bit task range of one task list", (unsigned long long)total);  // bmsp_spgemm retries in panels
+    if (total >= (1ull << 32))  // bmsp_spgemm retries in block-row panels (shard.hip: spgemm_paneled)
+        throw TaskRangeExceeded(BMSP_ERR_LIMIT, std::to_string(total) + " candidate block pairs exceed the 32-bit range of one task list");
 
     // T_3 + T_4: expansion fused with the bitmap filter
     const int jbits = std::max(1, ceil_log2_u64((uint64_t)B->num_block_cols()));
