@@ -24,6 +24,21 @@ t0 = time.time(); A2 = B.BmSpMatrix.load(cache); B.synchronize(); t1 = time.time
 print("bmsp_matrix_load: %.0f ms" % ((t1 - t0) * 1e3))
 for x, y in zip(A.host_arrays(), A2.host_arrays()):
     assert np.array_equal(x, y)
+# device-resident conversions
+def timed(f, reps=5):
+    f(); B.synchronize()
+    t0 = time.time()
+    for _ in range(reps): out = f()
+    B.synchronize()
+    return (time.time() - t0) * 1e3 / reps, out
+ms, csr = timed(lambda: A.to_csr_device())
+print("bmsp_matrix_to_csr_device: %.2f ms" % ms)
+ms, A3 = timed(lambda: B.BmSpMatrix.from_csr_device(n, n, *csr))
+print("bmsp_matrix_from_csr_device: %.2f ms" % ms)
+for x, y in zip(A.host_arrays(), A3.host_arrays()):
+    assert np.array_equal(x, y)
+ms, _ = timed(lambda: B.BmSpMatrix.from_coo(n, n, r, c, v))
+print("bmsp_matrix_from_coo (host triples -> device build): %.2f ms" % ms)
 try:
     import oracle as O
     t0 = time.time(); coo = O.mtx_read(path); t1 = time.time()
