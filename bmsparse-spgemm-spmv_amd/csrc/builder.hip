@@ -569,6 +569,89 @@ struct RowOfEntry {
 };
 }  // namespace
 
+namespace {
+struct PackRowCol {
+    const int *rows, *cols;
+    uint64_t *keys;
+    uint32_t *idx;
+    __device__ void operator()(uint64_t i) const
+    {
+        keys[i] = ((uint64_t)(uint32_t)rows[i] << 32) | (uint32_t)cols[i];
+        idx[i] = (uint32_t)i;
+    }
+};
+// bmSpMatrix<T>::compare (src/bmSpMatrix.cu:381-432), one thread per stored value of m: find the comparand entry with the same
+// coordinates (first of equal ones, as the stable host sort picks), add the relative error, count the entries m holds alone
+__global__ __launch_bounds__(kThreads) void compare_kernel(const uint64_t *__restrict__ m_rc, const double *__restrict__ m_vals, uint64_t n,
+                                                           const uint64_t *__restrict__ c_keys, const uint32_t *__restrict__ c_idx,
+                                                           const double *__restrict__ c_vals, uint64_t nc, double *__restrict__ err_sum,
+                                                           unsigned long long *__restrict__ missing)
+{
+    __shared__ double s_err[4];
+    __shared__ unsigned long long s_miss[4];
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    double term = 0.0;
+    unsigned long long miss = 0;
+    if (i < n) {
+        const uint64_t key = m_rc[i];
+        uint64_t lo = 0, hi = nc;
+        while (lo < hi) {
+            const uint64_t mid = lo + ((hi - lo) >> 1);
+            if (c_keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= nc || c_keys[lo] != key) {
+            miss = 1;
+        } else {
+            const double eps = 1e-8;  // :403
+            const double cv = c_vals[c_idx[lo]], mv = m_vals[i];
+            const double e = fabs(cv) < eps ? 0.0 : cv, r = fabs(mv) < eps ? 0.0 : mv;
+            term = fabs(e - r) / fmax(fabs(e), eps);  // :418
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        term += __shfl_xor(term, d, kWave);
+        miss += __shfl_xor(miss, d, kWave);
+    }
+    if (lane_id() == 0) { s_err[wave_id()] = term; s_miss[wave_id()] = miss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(err_sum, s_err[0] + s_err[1] + s_err[2] + s_err[3]);
+        atomicAdd(missing, s_miss[0] + s_miss[1] + s_miss[2] + s_miss[3]);
+    }
+}
+}  // namespace
+
+void matrix_compare_device(bmsp_matrix_s *m, int64_t nnz, const int *d_rows, const int *d_cols, const double *d_vals, double *mean_rel_err,
+                           int64_t *missing, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)m->nnz, nc = (uint64_t)nnz;
+    if (nc >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "comparand with 2^32 or more entries");
+    *mean_rel_err = 0.0;
+    if (missing) *missing = 0;
+    if (n == 0) return;
+    DevBuf<uint64_t> rc(n), k0(nc), k1(nc);
+    DevBuf<double> mv(n);
+    DevBuf<uint32_t> i0(nc), i1(nc);
+    matrix_to_coo_device(m, rc.p, mv.p, st);
+    PingPong<uint64_t> kk{k0.p, k1.p};
+    PingPong<uint32_t> ii{i0.p, i1.p};
+    if (nc) {
+        device_for_each(PackRowCol{d_rows, d_cols, k0.p, i0.p}, nc, st);
+        device_radix_sort_pairs<uint32_t>(kk, ii, nc, 0, 64, st);
+    }
+    DevBuf<double> err(1);
+    DevBuf<unsigned long long> miss(1);
+    BMSP_HIP(hipMemsetAsync(err.p, 0, 8, st));
+    BMSP_HIP(hipMemsetAsync(miss.p, 0, 8, st));
+    hipLaunchKernelGGL(compare_kernel, grid_for(n), dim3(kThreads), 0, st, rc.p, mv.p, n, kk.cur, ii.cur, d_vals, nc, err.p, miss.p);
+    BMSP_CHECK_LAUNCH();
+    const double sum = read_back(err.p, st);
+    const unsigned long long ms = read_back(miss.p, st);
+    *mean_rel_err = sum / (double)n;  // "Final:" (:429)
+    if (missing) *missing = (int64_t)ms;
+}
+
 void matrix_to_coo_device_split(bmsp_matrix_s *m, int *d_rows, int *d_cols, double *d_vals, hipStream_t st)
 {
     const uint64_t n = (uint64_t)m->nnz;

@@ -400,6 +400,18 @@ int bmsp_matrix_from_csr_device(int num_rows, int num_cols, int64_t nnz, const i
     BMSP_API_END
 }
 
+int bmsp_matrix_compare_device(bmsp_matrix_t m, int64_t nnz, const int *d_rows, const int *d_cols, const double *d_vals, double *mean_rel_err,
+                               int64_t *missing, void *stream)
+{
+    BMSP_API_BEGIN
+    need(m, "matrix"); need(mean_rel_err, "mean_rel_err");
+    if (nnz < 0) fail(BMSP_ERR_INVALID, "negative size");
+    if (nnz) { need(d_rows, "rows"); need(d_cols, "cols"); need(d_vals, "vals"); }
+    if (m->ownership == 2 && m->view_block_begin) fail(BMSP_ERR_UNSUPPORTED, "row-panel views cannot be expanded; compare the parent");
+    matrix_compare_device(m, nnz, d_rows, d_cols, d_vals, mean_rel_err, missing, as_stream(stream));
+    BMSP_API_END
+}
+
 int bmsp_matrix_compare(bmsp_matrix_t m, int64_t nnz, const int *rows, const int *cols, const double *vals, double *mean_rel_err,
                         int64_t *missing)
 {

@@ -62,6 +62,8 @@ void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st);
 void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st);
 void matrix_to_coo_device_split(bmsp_matrix_s *m, int *d_rows, int *d_cols, double *d_vals, hipStream_t st);
 void matrix_to_csr_device(bmsp_matrix_s *m, int *d_row_offsets, int *d_cols, double *d_vals, hipStream_t st);
+void matrix_compare_device(bmsp_matrix_s *m, int64_t nnz, const int *d_rows, const int *d_cols, const double *d_vals, double *mean_rel_err,
+                           int64_t *missing, hipStream_t st);
 bmsp_matrix_s *build_from_device_csr(int num_rows, int num_cols, int64_t nnz, const int *d_row_offsets, const int *d_cols, const double *d_vals,
                                      int transposed, bmsp_dtype dtype, hipStream_t st);
 void free_matrix(bmsp_matrix_s *m);

@@ -27,7 +27,7 @@ SYMBOLS = [
     "bmsp_event_create", "bmsp_event_record", "bmsp_event_elapsed_ms", "bmsp_event_destroy",
     "bmsp_matrix_from_mtx", "bmsp_matrix_from_coo", "bmsp_matrix_from_coo_device", "bmsp_matrix_from_arrays",
     "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
-    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_spmv", "bmsp_spmm", "bmsp_spgemm", "bmsp_segsort_u64",
+    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmm", "bmsp_spgemm", "bmsp_segsort_u64",
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
     "bmsp_csr_spmv", "bmsp_csr_free",
@@ -94,6 +94,7 @@ def lib():
         L.bmsp_matrix_to_coo_device.argtypes = [vp, vp, vp, vp, vp]
         L.bmsp_matrix_to_csr_device.argtypes = [vp, vp, vp, vp, vp]
         L.bmsp_matrix_from_csr_device.argtypes = [i, i, i64, vp, vp, vp, i, i, vp, p(vp)]
+        L.bmsp_matrix_compare_device.argtypes = [vp, i64, vp, vp, vp, p(C.c_double), p(i64), vp]
         L.bmsp_matrix_compare.argtypes = [vp, i64, vp, vp, vp, p(C.c_double), p(i64)]
         L.bmsp_spmv.argtypes = [vp, vp, vp, i, vp]
         L.bmsp_spmm.argtypes = [vp, vp, i64, vp, i64, i, vp]
@@ -326,6 +327,12 @@ class BmSpMatrix:
         err, miss = C.c_double(), C.c_int64()
         check(lib().bmsp_matrix_compare(self.h, rows.size, rows.ctypes.data, cols.ctypes.data, vals.ctypes.data,
                                         C.byref(err), C.byref(miss)))
+        return err.value, miss.value
+
+    def compare_device(self, rows, cols, vals, stream=None):
+        """rows / cols int32, vals float64 DeviceArrays."""
+        err, miss = C.c_double(), C.c_int64()
+        check(lib().bmsp_matrix_compare_device(self.h, rows.n, rows.ptr, cols.ptr, vals.ptr, C.byref(err), C.byref(miss), stream))
         return err.value, miss.value
 
     def row_panel(self, brow_begin, brow_end):

@@ -131,6 +131,9 @@ int bmsp_matrix_from_csr_device(int num_rows, int num_cols, int64_t nnz, const i
  * that the comparand lacks (the reference would walk out of bounds). */
 int bmsp_matrix_compare(bmsp_matrix_t m, int64_t nnz, const int *rows, const int *cols, const double *vals,
                         double *mean_rel_err, int64_t *missing);
+/* the same comparison with a device-resident comparand, entirely on the device (large products) */
+int bmsp_matrix_compare_device(bmsp_matrix_t m, int64_t nnz, const int *d_rows, const int *d_cols, const double *d_vals,
+                               double *mean_rel_err, int64_t *missing, void *stream);
 
 /* ---- operators ------------------------------------------------------------------------------ */
 

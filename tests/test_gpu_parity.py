@@ -752,6 +752,31 @@ def test_spgemm_beyond_32bit_candidates(bmsp):
     assert np.all(np.abs(y_chain - y_prod) <= 2.0 ** -10 * mag + 1e-4)
 
 
+def test_compare_on_device(bmsp):
+    """bmSpMatrix::compare with a device-resident comparand (SURVEY 8(f)2): same figure as the host comparison -- zero for an
+    identical matrix, the injected error for perturbed values, `missing` for entries the comparand lacks; duplicates and extra
+    comparand entries behave as on the host."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(12, 6)
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    At = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True)
+    Cm, _ = bmsp.spgemm(A, At)
+    rr, cc, vv = Cm.to_coo()
+    dev = lambda a, t: bmsp.DeviceArray.from_host(np.ascontiguousarray(a, dtype=t))
+    assert Cm.compare_device(dev(rr, np.int32), dev(cc, np.int32), dev(vv, np.float64)) == (0.0, 0)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(rr.size)                 # the comparand need not be sorted
+    v2 = vv.copy(); v2[::7] *= 1.0 + 1e-3           # relative error 1e-3 on every 7th entry
+    keep = np.ones(rr.size, bool); keep[5::11] = False  # entries the comparand lacks
+    extra_r = np.array([n - 1, n - 1], np.int32); extra_c = np.array([0, 0], np.int32)  # entries only the comparand has (twice)
+    r3 = np.concatenate([rr[perm][keep[perm]], extra_r]); c3 = np.concatenate([cc[perm][keep[perm]], extra_c])
+    v3 = np.concatenate([v2[perm][keep[perm]], [9.0, 7.0]])
+    host_err, host_miss = Cm.compare(r3, c3, v3)
+    dev_err, dev_miss = Cm.compare_device(dev(r3, np.int32), dev(c3, np.int32), dev(v3, np.float64))
+    assert dev_miss == host_miss == int((~keep).sum())
+    assert abs(dev_err - host_err) <= 1e-12 * max(1.0, host_err) and host_err > 0
+
+
 def test_borrowed_arrays_multiply(oracle, bmsp):
     """bmsp_matrix_from_arrays with ownership 2 (caller keeps the arrays), every MAC kernel."""
     from pybmsp import gen
