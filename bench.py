@@ -2,21 +2,25 @@
 """bench.py -- headline benchmark of the MI355X-native bmSparse engine.
 
 metric (BASELINE.json): "SpMV effective GB/s + SpGEMM GFLOP/s on SuiteSparse; % HBM/MFMA roofline".
-The ONE JSON line carries the SpMV figure as `value` (configs[1]: bmSparse SpMV fp32 on webbase-1M, 1 GPU) and the
-SpGEMM figures (configs[2], configs[3]) in `spgemm`.
+The ONE JSON line carries the SpMV figure as `value` (configs[1]: bmSparse SpMV fp32 on webbase-1M, 1 GPU), the same sweep
+on two denser structures under `spmv_structures`, the SpGEMM figures (configs[2], configs[3] and a dense-tile ceiling run)
+under `spgemm`, and the CPU baselines (cusp::multiply restatement: SpMV, SpGEMM, and configs[0] -- host SpMV on a cant-sized
+matrix) under `cpu_baseline`.
 
 A step = one SpMV sweep u = A*v over one resident matrix.  SuiteSparse files cannot be downloaded here; unless
 `--mtx-dir` holds webbase-1M.mtx the workload is the synthetic stand-in of SURVEY.md 8(d): R-MAT scale 20, edge factor
 2, identity added (1 048 576 rows, ~3.13 M nnz -- webbase-1M has 1 000 005 rows, 3 105 536 nnz).  The matrix in bmSparse
 form is ~70 MB and would sit in the 256 MiB Infinity Cache, so the timed loop rotates over enough device-resident copies
 (> 512 MiB in total) that every sweep streams from HBM; the cache-warm figure is reported beside it as
-`warm_ms_per_step`.  Inputs are resident in HBM before the timed region starts.
+`warm_ms_per_step`.  Inputs are resident in HBM and every copy's cached sweep plan is built (bmsp_matrix_prepare + one
+untimed sweep per copy) before the timed region starts, whatever --warmup is.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): every rank sweeps its own copies (fixed work per GPU,
 no data-path collective; weak scaling); value = bytes swept by all ranks / max-over-ranks time.  The row-panel-sharded
 SpGEMM with its RCCL allgatherv (configs[4]) is timed in the same run and reported under `spgemm_sharded`.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -38,12 +42,14 @@ def parse():
     ap.add_argument("--mtx-dir", default=os.environ.get("BMSP_MTX_DIR", ""))
     ap.add_argument("--scale", type=int, default=20, help="R-MAT scale of the synthetic SpMV workload")
     ap.add_argument("--edge-factor", type=float, default=2.0)
-    ap.add_argument("--spmv-matrix", default="", help="experiment override: banded:N:HB | rmat:SCALE:EF | cage:N")
+    ap.add_argument("--spmv-matrix", default="", help="experiment override: banded:N:HB | rmat:SCALE:EF | cage:N | fem:SIDE")
     ap.add_argument("--batched", type=int, default=-1, help="-1 auto, 0 / 1 force the SpMV variant")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-spgemm", action="store_true")
+    ap.add_argument("--skip-structures", action="store_true", help="skip the banded SpMV structures")
     ap.add_argument("--skip-vendor", action="store_true", help="skip the rocSPARSE comparison column")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--only-spgemm", default="", help="experiment: run only the SpGEMM case whose tag contains this (fem | cage | dense)")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="bound on the CPU-baseline work, all legs together")
     return ap.parse_args()
 
 
@@ -59,20 +65,67 @@ def bmsp_spmv_bytes(info, itemsize=4):
     return 24 * info["block_num"] + itemsize * info["nnz"] + 4 * (nbr + 1) + itemsize * info["num_cols"] + itemsize * info["num_rows"]
 
 
+def parse_matrix_spec(gen, spec):
+    kind, *a = spec.split(":")
+    return {"banded": lambda: gen.banded(int(a[0]), int(a[1])), "rmat": lambda: gen.rmat(int(a[0]), float(a[1])),
+            "cage": lambda: gen.cage_like(int(a[0])), "fem": lambda: gen.fem_like(int(a[0]))}[kind]()
+
+
 def load_spmv_workload(args):
     from pybmsp import gen
-    import numpy as np
     path = os.path.join(args.mtx_dir, "webbase-1M.mtx") if args.mtx_dir else ""
     if path and os.path.exists(path):
         return {"name": "webbase-1M (SuiteSparse file)", "path": path}
     if args.spmv_matrix:
-        kind, *a = args.spmv_matrix.split(":")
-        coo = {"banded": lambda: gen.banded(int(a[0]), int(a[1])), "rmat": lambda: gen.rmat(int(a[0]), float(a[1])),
-               "cage": lambda: gen.cage_like(int(a[0]))}[kind]()
-        return {"name": args.spmv_matrix + " (experiment)", "coo": coo}
+        return {"name": args.spmv_matrix + " (experiment)", "coo": parse_matrix_spec(gen, args.spmv_matrix)}
     n, _, r, c, v = gen.rmat(args.scale, args.edge_factor, seed=1)
     return {"name": "rmat(scale=%d, edge_factor=%g)+I, stand-in for webbase-1M" % (args.scale, args.edge_factor),
             "coo": (n, n, r, c, v)}
+
+
+def profile_json(pattern, key):
+    """newest committed rocprofv3 summary matching profiles/<pattern>; None when there is none"""
+    val = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", pattern))):
+        try:
+            val = json.load(open(f)).get(key, val)
+        except Exception:
+            pass
+    return val
+
+
+class SpmvSet:
+    """`copies` device-resident clones of one matrix (rotated so that sweeps stream from HBM), plans built, every copy swept once"""
+
+    def __init__(self, B, np, first, x_kind="ones", min_bytes=512 * 2 ** 20):
+        from pybmsp import gen
+        self.B, self.L = B, B.lib()
+        self.info = first.info()
+        self.alg_bytes = bmsp_spmv_bytes(self.info)
+        self.eff_bytes = csr_bytes(self.info["num_rows"], self.info["nnz"])
+        self.copies = max(2, int(np.ceil(min_bytes / self.alg_bytes)) + 1)
+        self.mats = [first] + [first.clone() for _ in range(self.copies - 1)]
+        self.x = B.DeviceArray.from_host(gen.spmv_x(self.info["num_cols"], x_kind))  # v = 1 (SPMV.cu:279-281)
+        self.ys = [B.DeviceArray(self.info["num_rows"], np.float32) for _ in range(self.copies)]
+        for m in self.mats:
+            m.prepare(1)
+        for k in range(self.copies):  # plan builds and first-touch effects stay out of every timed region
+            self.step(k, 0)
+        B.synchronize()
+
+    def step(self, i, variant):
+        k = i % self.copies
+        self.B.check(self.L.bmsp_spmv(self.mats[k].h, self.x.ptr, self.ys[k].ptr, variant, None))
+
+    def timed(self, steps, variant, rotate=True):
+        B = self.B
+        e0, e1 = B.Event(), B.Event()
+        e0.record()
+        for i in range(steps):
+            self.step(i if rotate else 0, variant)
+        e1.record()
+        B.synchronize()
+        return e0.elapsed_ms(e1) / steps
 
 
 def main():
@@ -118,34 +171,21 @@ def main():
     wl = load_spmv_workload(args)
     if "path" in wl:
         first = B.BmSpMatrix.from_mtx(wl["path"])
-        mk = lambda: B.BmSpMatrix.from_mtx(wl["path"])
     else:
         n, _, r, c, v = wl["coo"]
         first = B.BmSpMatrix.from_coo(n, n, r, c, v)
-        mk = lambda: B.BmSpMatrix.from_coo(n, n, r, c, v)
-    info = first.info()
-    alg_bytes = bmsp_spmv_bytes(info)
-    eff_bytes = csr_bytes(info["num_rows"], info["nnz"])
-    copies = max(2, int(np.ceil(512 * 2 ** 20 / alg_bytes)) + 1)
-    mats = [first] + [mk() for _ in range(copies - 1)]
-    x = B.DeviceArray.from_host(gen.spmv_x(info["num_cols"], "ones"))  # v = 1 (SPMV.cu:279-281)
-    ys = [B.DeviceArray(info["num_rows"], np.float32) for _ in range(copies)]
-    avg_blocks_per_row = info["block_num"] / max(1, (info["num_rows"] + 7) // 8)
+    S = SpmvSet(B, np, first)
+    info, alg_bytes, eff_bytes, copies = S.info, S.alg_bytes, S.eff_bytes, S.copies
     variant = args.batched if args.batched >= 0 else 0
 
-    def step(i):
-        k = i % copies
-        B.check(L.bmsp_spmv(mats[k].h, x.ptr, ys[k].ptr, variant, None))
-
-    L = B.lib()
     for i in range(args.warmup):
-        step(i)
+        S.step(i, variant)
     sync(); barrier(); sync()
     e0, e1 = B.Event(), B.Event()
     t0 = time.perf_counter()
     e0.record()
     for i in range(args.steps):
-        step(i)
+        S.step(i, variant)
     e1.record()
     sync(); barrier()
     wall = time.perf_counter() - t0
@@ -158,15 +198,8 @@ def main():
     value = world * eff_bytes * args.steps / wall / 1e9  # every rank sweeps the same amount of its own data
 
     # cache-warm sweep (one copy only), for information
-    for i in range(10):
-        L.bmsp_spmv(mats[0].h, x.ptr, ys[0].ptr, variant, None)
-    sync()
-    w0, w1 = B.Event(), B.Event()
-    w0.record()
-    for i in range(args.steps):
-        L.bmsp_spmv(mats[0].h, x.ptr, ys[0].ptr, variant, None)
-    w1.record()
-    warm_ms = w0.elapsed_ms(w1) / args.steps
+    S.timed(10, variant, rotate=False)
+    warm_ms = S.timed(args.steps, variant, rotate=False)
 
     kern_ms = dev_ms / args.steps  # HIP events on the launch stream, over the timed region
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -174,9 +207,7 @@ def main():
     # it was collected on
     traffic = None
     if "coo" in wl and not args.spmv_matrix and args.scale == 20 and args.edge_factor == 2.0:
-        import glob
-        for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_spmv_webbase_like*_traffic.json"))):
-            traffic = json.load(open(f))["traffic_bytes_per_launch"]
+        traffic = profile_json("r*_spmv_webbase_like*_traffic.json", "traffic_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "spmv_sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(kern_ms, 5)}
@@ -186,18 +217,26 @@ def main():
            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic" if "coo" in wl else "suitesparse",
            "config": {"workload": "bmSparse SpMV fp32, " + wl["name"], "rows": info["num_rows"], "nnz": info["nnz"],
-                      "blocks": info["block_num"], "x": "ones", "variant": ["sweep (default)", "batched", "row-group"][variant],
+                      "blocks": info["block_num"], "values_per_tile": round(info["nnz"] / max(1, info["block_num"]), 3),
+                      "x": "ones", "variant": ["sweep (default)", "batched", "row-group"][variant],
                       "hbm_resident_copies_rotated": copies, "effective_bytes_per_spmv": eff_bytes},
            "warm_ms_per_step": round(warm_ms, 5), "warm_effective_GBs": round(eff_bytes / (warm_ms * 1e-3) / 1e9, 1),
            "roofline": roofline}
 
-    # ---------------- SpGEMM (configs[2], configs[3]) on rank 0 / single GPU ----------------
+    # ---------------- the same sweep on denser structures (driver-verifiable roofline fractions) ----------------
+    if not args.skip_structures and not use_dist and not args.spmv_matrix:
+        out["spmv_structures"] = bench_spmv_structures(B, gen, np, S)
+    mats0, x0, y0 = S.mats[0], S.x, S.ys[0]
+    if not use_dist:
+        del S.mats[1:], S.ys[1:]
+
+    # ---------------- SpGEMM (configs[2], configs[3], dense-tile ceiling) on rank 0 / single GPU ----------------
     if not args.skip_spgemm and not use_dist:
         out["spgemm"] = bench_spgemm(B, gen, np, args)
     if use_dist and not args.skip_spgemm:
         out["spgemm_sharded"] = bench_spgemm_sharded(B, gen, np, torch, dist, rank, world)
     if use_dist:
-        out["spmv_sharded"] = bench_spmv_sharded(B, np, torch, dist, rank, world, mats[0], x, ys[0])
+        out["spmv_sharded"] = bench_spmv_sharded(B, np, torch, dist, rank, world, mats0, x0, y0)
 
     # ---------------- vendor comparison column (rocSPARSE CSR on the same matrices; reporting only) ----------------
     if rank == 0 and not use_dist and not args.skip_vendor:
@@ -216,23 +255,60 @@ def main():
         dist.destroy_process_group()
 
 
+def bench_spmv_structures(B, gen, np, headline):
+    """the three structures of VERDICT r1 item 3 in one line: the headline R-MAT (hyper-sparse tiles), banded half-bandwidth 8
+    (half-filled tiles) and banded half-bandwidth 32 (mostly full tiles).  Same kernel entry point, HBM-resident rotation,
+    per-launch time from HIP events."""
+    res = [{"structure": "headline (see config.workload)", "values_per_tile": round(headline.info["nnz"] / max(1, headline.info["block_num"]), 2)}]
+    cases = [("banded(1000000, half_bw=8)", lambda: gen.banded(1000000, 8)), ("banded(500000, half_bw=32)", lambda: gen.banded(500000, 32))]
+    for name, mk in cases:
+        n, _, r, c, v = mk()
+        first = B.BmSpMatrix.from_coo(n, n, r, c, v)
+        del r, c, v
+        S = SpmvSet(B, np, first, x_kind="cusp")
+        S.timed(10, 0)
+        ms = S.timed(60, 0)
+        ach = S.alg_bytes / (ms * 1e-3) / 1e9
+        res.append({"structure": name, "rows": S.info["num_rows"], "nnz": S.info["nnz"], "blocks": S.info["block_num"],
+                    "values_per_tile": round(S.info["nnz"] / max(1, S.info["block_num"]), 2), "hbm_resident_copies_rotated": S.copies,
+                    "avg_launch_ms": round(ms, 5), "algorithmic_bytes_per_launch": S.alg_bytes,
+                    "effective_GBs": round(S.eff_bytes / (ms * 1e-3) / 1e9, 1),
+                    "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}})
+        del S, first
+        B.check(B.lib().bmsp_trim_pool())
+    return res
+
+
+SPGEMM_CASES = [
+    # tag, workload name, generator, dtype name, tc_version, SuiteSparse file it stands in for, profiles/ tag
+    ("fem", "2cubes_sphere-like fem_like(47^3 grid, poisson27pt, windowed random renumbering)", lambda g: g.fem_like(47, "27pt"), "F32", 5, "2cubes_sphere.mtx", "spgemm_fem_like"),
+    ("cage", "cage12-like local+random(130228, 15.6/row)", lambda g: g.cage_like(130228, 15.6), "F16", 4, "cage12.mtx", "spgemm_cage_like"),
+    ("dense", "dense-tile ceiling: banded(131072, half_bw=32), full 8x8 tiles", lambda g: g.banded(131072, 32), "F16", 4, None, "spgemm_dense_tiles"),
+]
+
+
 def bench_spgemm(B, gen, np, args):
-    """A x A on the synthetic stand-ins of 2cubes_sphere (fp32, vector-ALU block-MAC) and cage12 (fp16, MFMA block-MAC)."""
+    """A x A on the synthetic stand-ins of 2cubes_sphere (fp32, vector-ALU block-MAC) and cage12 (fp16, MFMA block-MAC), plus a
+    dense-tile input (every tile full, ~9 tasks per C block) that separates the block-MAC kernel's own ceiling from the inputs'
+    sparsity."""
     res = []
-    cases = [("2cubes_sphere-like banded(101492, half_bw=8)", gen.banded(101492, 8), B.F32, 5, "2cubes_sphere.mtx"),
-             ("cage12-like local+random(130228, 15.6/row)", gen.cage_like(130228, 15.6), B.F16, 4, "cage12.mtx")]
-    for name, coo, dtype, tc, fname in cases:
-        path = os.path.join(args.mtx_dir, fname) if args.mtx_dir else ""
+    for tag, name, mk, dtn, tc, fname, ptag in SPGEMM_CASES:
+        if args.only_spgemm and args.only_spgemm not in tag:
+            continue
+        dtype = getattr(B, dtn)
+        path = os.path.join(args.mtx_dir, fname) if (args.mtx_dir and fname) else ""
         if path and os.path.exists(path):
             A = B.BmSpMatrix.from_mtx(path, False, dtype)
             At = B.BmSpMatrix.from_mtx(path, True, dtype)
             name = fname + " (SuiteSparse file)"
         else:
-            n, _, r, c, v = coo
+            n, _, r, c, v = mk(gen)
             A = B.BmSpMatrix.from_coo(n, n, r, c, v, dtype=dtype)
             At = B.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=dtype)
+            del r, c, v
+        A.prepare(2); At.prepare(2)
         runs = []
-        for it in range(12):  # two calls warm the pool and the per-matrix caches; median of the next ten (BASELINE.md section 3)
+        for it in range(9):  # two calls warm the pool and the per-matrix caches; median of the next seven (BASELINE.md section 3)
             Cm, st = B.spgemm(A, At, mode=B.SORT_AUTO, tc_version=tc)
             if it >= 2:
                 runs.append(st)
@@ -245,15 +321,24 @@ def bench_spgemm(B, gen, np, args):
         t_mac = best["t_us"][7] * 1e-6
         f_mac = 1024.0 * best["surviving_tasks"]
         peak = MFMA_F16_PEAK_TFLOPS if dtype == B.F16 else FP32_PEAK_TFLOPS
+        roof = {"bound": "mfma" if dtype == B.F16 else "valu", "kernel": "block_mac", "achieved": round(f_mac / t_mac / 1e12, 3),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(f_mac / t_mac / 1e12 / peak, 5),
+                "traffic": profile_json("r*_%s_traffic.json" % ptag, "traffic_bytes_per_launch")}
+        mu = profile_json("r*_%s_mfma.json" % ptag, "mfma_util")
+        if mu is not None:
+            roof["mfma_util"] = mu  # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), from the committed PMC pass
         res.append({"workload": "bmSparse SpGEMM A*A %s, %s" % ("fp16 MFMA block-MAC" if dtype == B.F16 else "fp32", name),
                     "rows": info["num_rows"], "nnz": info["nnz"], "blocks": info["block_num"],
+                    "values_per_tile": round(info["nnz"] / max(1, info["block_num"]), 2),
                     "tasks": best["task_list_size"], "surviving_tasks": best["surviving_tasks"], "c_blocks": best["c_blocks"],
-                    "c_nnz": best["c_nnz"], "scalar_products": int(P), "total_ms": round(t_total * 1e3, 3), "timing": "median of 10 products",
+                    "tasks_per_c_block": round(best["surviving_tasks"] / max(1, best["c_blocks"]), 2),
+                    "c_nnz": best["c_nnz"], "scalar_products": int(P), "total_ms": round(t_total * 1e3, 3), "timing": "median of 7 products",
                     "gflops": round(2.0 * P / t_total / 1e9, 2),
                     "stage_us": {k: round(best["t_us"][i], 1) for k, i in (("T_1", 1), ("T_2", 2), ("T_3", 3), ("T_4", 4), ("T_5", 5), ("T_6", 6), ("T_9", 9), ("T_7", 7))},
                     "sort_path": "segmented" if best["sort_path"] else "global radix",
-                    "roofline": {"bound": "mfma" if dtype == B.F16 else "valu", "kernel": "block_mac", "achieved": round(f_mac / t_mac / 1e12, 3),
-                                 "peak": peak, "unit": "TFLOP/s", "frac": round(f_mac / t_mac / 1e12 / peak, 5), "traffic": None}})
+                    "roofline": roof})
+        del A, At
+        B.check(B.lib().bmsp_trim_pool())
     return res
 
 
@@ -280,7 +365,7 @@ def vendor_column(np, gen, wl, eff_bytes, args):
         m, ptr, col, val = csr_of(wl["coo"])
         x = np.ones(m.shape[1], np.float32); y = np.zeros(m.shape[0], np.float32)
         best = None
-        for alg, name in ((0, "default"), (1, "adaptive"), (2, "rowsplit"), (3, "lrb")):
+        for alg, name in ((1, "adaptive"), (3, "lrb")):
             ms, pre = C.c_double(), C.c_double()
             rc = V.vendor_csr_spmv(m.shape[0], m.shape[1], m.nnz, ptr.ctypes.data, col.ctypes.data, val.ctypes.data, x.ctypes.data, y.ctypes.data,
                                    alg, 200, C.byref(ms), C.byref(pre))
@@ -291,8 +376,10 @@ def vendor_column(np, gen, wl, eff_bytes, args):
                            "effective_GBs": round(eff_bytes / (best[1] * 1e-3) / 1e9, 1), "y_checksum": float(y.sum())}
     if not args.skip_spgemm:
         res["spgemm"] = []
-        for name, coo in (("2cubes_sphere-like banded(101492, half_bw=8)", gen.banded(101492, 8)), ("cage12-like local+random(130228, 15.6/row)", gen.cage_like(130228, 15.6))):
-            m, ptr, col, val = csr_of(coo)
+        for tag, name, mk, dtn, tc, fname, ptag in SPGEMM_CASES:
+            if tag == "dense" or (args.only_spgemm and args.only_spgemm not in tag):
+                continue
+            m, ptr, col, val = csr_of(mk(gen))
             ms, first, nz, sm = C.c_double(), C.c_double(), i64(), C.c_double()
             rc = V.vendor_csr_spgemm(m.shape[0], m.shape[1], m.shape[1], m.nnz, ptr.ctypes.data, col.ctypes.data, val.ctypes.data, m.nnz, ptr.ctypes.data,
                                      col.ctypes.data, val.ctypes.data, 5, C.byref(ms), C.byref(first), C.byref(nz), C.byref(sm))
@@ -363,20 +450,7 @@ def bench_spgemm_sharded(B, gen, np, torch, dist, rank, world):
             "panel_tasks": best[1]["tasks"]}
 
 
-def cpu_baseline(wl, eff_bytes, args):
-    """oracle (`port` of cusp::multiply, csr_spmv.h:56-73 + the OpenMP row-parallel variant) on this box's host cores,
-    on the same matrix and x; bounded to ~cpu-seconds of work."""
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import numpy as np
-    import oracle as O
-    from pybmsp import gen
-    if "path" in wl:
-        coo = O.mtx_read(wl["path"], strict=True)
-    else:
-        n, _, r, c, v = wl["coo"]
-        coo = O.Coo(n, n, r, c, v)
-    A = O.csr_from_coo(coo)
-    x = gen.spmv_x(A.num_cols, "ones")
+def host_threads(O):
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -387,24 +461,80 @@ def cpu_baseline(wl, eff_bytes, args):
             avail = max(1, min(avail, int(int(q) / int(per))))
     except Exception:
         pass
-    th = max(1, min(O.max_threads(), avail, 64))
+    return max(1, min(O.max_threads(), avail, 64))
+
+
+def time_cpu(fn, budget_s, max_iters=2000, min_iters=3):
+    fn()
+    t0 = time.perf_counter()
+    fn()
+    one = max(1e-6, time.perf_counter() - t0)
+    iters = int(min(max_iters, max(min_iters, budget_s / one)))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    return (time.perf_counter() - t0) / iters, iters
+
+
+def cpu_baseline(wl, eff_bytes, args):
+    """oracle (`port` of cusp::multiply) on this box's host cores, bounded to ~cpu-seconds of work in total:
+      * CSR SpMV (csr_spmv.h:56-73 + the OpenMP row-parallel variant) on the headline matrix and x  -> value
+      * CSR Gustavson SpGEMM (csr_spgemm.h:39-157, omp/.../csr_spgemm.h:40-157), A*A on both SpGEMM workloads -> `spgemm`
+      * configs[0]: the host CSR SpMV on a cant-sized FEM stand-in (62 451 rows, ~4.0 M nnz), no GPU involved -> `cant_like`"""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import numpy as np
+    import oracle as O
+    from pybmsp import gen
+    th = host_threads(O)
+    budget = args.cpu_seconds
+    if "path" in wl:
+        coo = O.mtx_read(wl["path"], strict=True)
+    else:
+        n, _, r, c, v = wl["coo"]
+        coo = O.Coo(n, n, r, c, v)
+    A = O.csr_from_coo(coo)
+    x = gen.spmv_x(A.num_cols, "ones")
     res = {}
     for name, t in (("omp", th), ("seq", 1)):
-        O.csr_spmv(A, x, t)
-        t0 = time.perf_counter()
-        O.csr_spmv(A, x, t)
-        one = max(1e-6, time.perf_counter() - t0)
-        iters = int(min(2000, max(10, (args.cpu_seconds / 2) / one)))
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            O.csr_spmv(A, x, t)
-        dt = (time.perf_counter() - t0) / iters
+        dt, iters = time_cpu(lambda: O.csr_spmv(A, x, t), budget * 0.12, min_iters=10)
         res[name] = (eff_bytes / dt / 1e9, iters, dt)
+    used = th
     if res["seq"][0] > res["omp"][0]:  # oversubscribed box: the single-thread figure is the better baseline
-        res["omp"], th = res["seq"], 1
-    return {"value": round(res["omp"][0], 2), "unit": "GB/s", "cores": th, "kind": "port",
-            "sample": "CSR SpMV (cusp::multiply restatement, OpenMP row-parallel) on the same matrix and x, %d iterations, %.2f ms each; "
-                      "single-thread: %.2f GB/s over %d iterations" % (res["omp"][1], res["omp"][2] * 1e3, res["seq"][0], res["seq"][1])}
+        res["omp"], used = res["seq"], 1
+    out = {"value": round(res["omp"][0], 2), "unit": "GB/s", "cores": used, "kind": "port",
+           "sample": "CSR SpMV (cusp::multiply restatement, OpenMP row-parallel) on the same matrix and x, %d iterations, %.2f ms each; "
+                     "single-thread: %.2f GB/s over %d iterations" % (res["omp"][1], res["omp"][2] * 1e3, res["seq"][0], res["seq"][1])}
+    # configs[0]: cusp::multiply SpMV on cant (62 451 rows, 4 007 383 nnz), host CPU path
+    cn, _, cr, cc, cv = gen.banded(62451, 32)
+    Ac = O.csr_from_coo(O.Coo(cn, cn, cr, cc, cv))
+    xc = gen.spmv_x(cn, "cusp")
+    cb = csr_bytes(cn, Ac.nnz)
+    legs = {}
+    for name, t in (("omp", th), ("seq", 1)):
+        dt, iters = time_cpu(lambda: O.csr_spmv(Ac, xc, t), budget * 0.08, min_iters=10)
+        legs[name] = {"GBs": round(cb / dt / 1e9, 2), "gflops": round(2.0 * Ac.nnz / dt / 1e9, 2), "ms": round(dt * 1e3, 4), "iterations": iters,
+                      "threads": t}
+    out["cant_like"] = {"workload": "configs[0] stand-in: cusp::multiply CSR SpMV, host only, banded(62451, half_bw=32): %d nnz (cant: 62 451 rows, "
+                                    "4 007 383 nnz)" % Ac.nnz, **legs}
+    if not args.skip_spgemm:
+        out["spgemm"] = []
+        for tag, name, mk, dtn, tc, fname, ptag in SPGEMM_CASES:
+            if tag == "dense" or (args.only_spgemm and args.only_spgemm not in tag):
+                continue
+            gn, _, gr, gc, gv = mk(gen)
+            G = O.csr_from_coo(O.Coo(gn, gn, gr, gc, gv))
+            legs = {}
+            prods = 0
+            for nm, t in (("omp", th), ("seq", 1)):
+                box = {}
+
+                def run():
+                    box["p"] = O.csr_spgemm(G, G, t)[1]
+                dt, iters = time_cpu(run, budget * 0.15, max_iters=50, min_iters=2)
+                prods = box["p"]
+                legs[nm] = {"gflops": round(2.0 * prods / dt / 1e9, 3), "ms": round(dt * 1e3, 2), "iterations": iters, "threads": t}
+            out["spgemm"].append({"workload": "cusp::multiply(csr,csr,csr) restatement (Gustavson), A*A fp32, " + name, "scalar_products": prods, **legs})
+    return out
 
 
 if __name__ == "__main__":

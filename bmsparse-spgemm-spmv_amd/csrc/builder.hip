@@ -375,6 +375,7 @@ void free_matrix(bmsp_matrix_s *m)
     pool_free(m->rowptr);
     pool_free(m->spmv_chunks);
     pool_free(m->block_meta);
+    pool_free(m->dense_tiles);
     delete m;
 }
 
@@ -407,6 +408,14 @@ void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st)
     if ((uint64_t)m->values_extent() >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "packed block records hold 32-bit value offsets");
     m->block_meta = (uint32_t *)pool_alloc(16 * (size_t)(m->block_num ? m->block_num : 1));
     if (m->block_num) device_for_each(PackBlockMeta{m->bmps, m->offsets, m->block_meta}, (uint64_t)m->block_num, st);
+}
+
+void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st)
+{
+    if ((uint64_t)m->values_extent() >= (1ull << 32) || m->block_num >= (1ll << 28)) return;  // pointer-based block-MAC: no records
+    ensure_block_meta(m, st);
+    // K = 32 MFMA block-MAC: A (normal layout) is always read from its dense copy, B from the dense copy or from the records
+    if (m->dtype == BMSP_F16 && m->block_num < (1ll << 25) && (!m->transposed || mac_mfma32_b_dense(m))) ensure_dense_tiles(m, st);
 }
 
 bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, const int *d_rows, const int *d_cols,
@@ -460,6 +469,9 @@ struct ExpandBlocks {
     double *vals;
     __device__ void operator()(uint64_t b) const
     {
+        // a row-panel view keeps offsets absolute into its parent's value array: values are read at the absolute offset, the
+        // outputs (sized by the view's own nnz) are written relative to the view's first value
+        const uint64_t base = offsets[0];
         uint64_t bmp = bmps[b], off = offsets[b];
         uint32_t brow = key_row(keys[b]), bcol = key_col(keys[b]);
         uint32_t k = 0;
@@ -468,8 +480,8 @@ struct ExpandBlocks {
             bmp &= ~(1ull << (63 - p));
             uint32_t hi = (uint32_t)p >> 3, lo = (uint32_t)p & 7u;
             uint32_t r = brow * 8 + (transposed ? lo : hi), c = bcol * 8 + (transposed ? hi : lo);
-            rc[off + k] = ((uint64_t)r << 32) | c;
-            vals[off + k] = (double)values[off + k];
+            rc[off - base + k] = ((uint64_t)r << 32) | c;
+            vals[off - base + k] = (double)values[off + k];
             k++;
         }
     }

@@ -359,12 +359,22 @@ int bmsp_matrix_block_row_ptr(bmsp_matrix_t m, const uint32_t **d_rowptr, int64_
     BMSP_API_END
 }
 
+int bmsp_matrix_prepare(bmsp_matrix_t m, int what, void *stream)
+{
+    BMSP_API_BEGIN
+    need(m, "matrix");
+    if (what & ~(BMSP_PREPARE_SPMV | BMSP_PREPARE_SPGEMM)) fail(BMSP_ERR_INVALID, "unknown prepare flags %d", what);
+    ensure_rowptr(m, as_stream(stream));
+    if (what & BMSP_PREPARE_SPMV) prepare_spmv(m, as_stream(stream));
+    if (what & BMSP_PREPARE_SPGEMM) prepare_spgemm_operand(m, as_stream(stream));
+    BMSP_API_END
+}
+
 int bmsp_matrix_to_coo_host(bmsp_matrix_t m, int *rows, int *cols, double *vals)
 {
     BMSP_API_BEGIN
     need(m, "matrix");
     if (m->nnz) { need(rows, "rows"); need(cols, "cols"); need(vals, "vals"); }
-    if (m->ownership == 2 && m->view_block_begin) fail(BMSP_ERR_UNSUPPORTED, "row-panel views cannot be expanded; expand the parent");
     matrix_to_coo_host(m, rows, cols, vals, nullptr);
     BMSP_API_END
 }
@@ -374,7 +384,6 @@ int bmsp_matrix_to_coo_device(bmsp_matrix_t m, int *d_rows, int *d_cols, double 
     BMSP_API_BEGIN
     need(m, "matrix");
     if (m->nnz) { need(d_rows, "rows"); need(d_cols, "cols"); need(d_vals, "vals"); }
-    if (m->ownership == 2 && m->view_block_begin) fail(BMSP_ERR_UNSUPPORTED, "row-panel views cannot be expanded; expand the parent");
     matrix_to_coo_device_split(m, d_rows, d_cols, d_vals, as_stream(stream));
     BMSP_API_END
 }
@@ -384,7 +393,6 @@ int bmsp_matrix_to_csr_device(bmsp_matrix_t m, int *d_row_offsets, int *d_cols, 
     BMSP_API_BEGIN
     need(m, "matrix"); need(d_row_offsets, "row_offsets");
     if (m->nnz) { need(d_cols, "cols"); need(d_vals, "vals"); }
-    if (m->ownership == 2 && m->view_block_begin) fail(BMSP_ERR_UNSUPPORTED, "row-panel views cannot be expanded; expand the parent");
     matrix_to_csr_device(m, d_row_offsets, d_cols, d_vals, as_stream(stream));
     BMSP_API_END
 }
@@ -407,7 +415,6 @@ int bmsp_matrix_compare_device(bmsp_matrix_t m, int64_t nnz, const int *d_rows, 
     need(m, "matrix"); need(mean_rel_err, "mean_rel_err");
     if (nnz < 0) fail(BMSP_ERR_INVALID, "negative size");
     if (nnz) { need(d_rows, "rows"); need(d_cols, "cols"); need(d_vals, "vals"); }
-    if (m->ownership == 2 && m->view_block_begin) fail(BMSP_ERR_UNSUPPORTED, "row-panel views cannot be expanded; compare the parent");
     matrix_compare_device(m, nnz, d_rows, d_cols, d_vals, mean_rel_err, missing, as_stream(stream));
     BMSP_API_END
 }
@@ -451,6 +458,14 @@ int bmsp_spmv(bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *st
     BMSP_API_BEGIN
     need(A, "A");
     spmv(A, d_v, d_u, variant, as_stream(stream));
+    BMSP_API_END
+}
+
+int bmsp_selftest_mfma_layout(int *mismatches)
+{
+    BMSP_API_BEGIN
+    need(mismatches, "mismatches");
+    *mismatches = mfma32_selftest(nullptr);
     BMSP_API_END
 }
 

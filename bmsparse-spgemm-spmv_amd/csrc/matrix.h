@@ -28,6 +28,8 @@ struct bmsp_matrix_s {
     size_t spmv_plan_off_cnt = 0, spmv_plan_off_carry = 0;
     // (bitmap, value offset) of every block as one 16-byte record, for kernels that gather both (block-MAC): built lazily
     uint32_t *block_meta = nullptr;  // block_num x {bmp lo, bmp hi, offset in elements, 0}
+    // fp16 matrices: every tile expanded to 64 halves in position order (128 B per block), for the K = 32 MFMA block-MAC: built lazily
+    void *dense_tiles = nullptr;
     // a row-panel view points into its parent
     int64_t view_block_begin = 0;
 
@@ -59,6 +61,12 @@ bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, co
 
 void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st);
 void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st);
+void ensure_dense_tiles(bmsp_matrix_s *m, hipStream_t st);
+bool mac_mfma32_supported(const bmsp_matrix_s *A, const bmsp_matrix_s *B);
+bool mac_mfma32_b_dense(const bmsp_matrix_s *B);
+void launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *task_begin, const uint32_t *c_of_wave, bmsp_matrix_s *A,
+                       bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);
+int mfma32_selftest(hipStream_t st);
 void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st);
 void matrix_to_coo_device_split(bmsp_matrix_s *m, int *d_rows, int *d_cols, double *d_vals, hipStream_t st);
 void matrix_to_csr_device(bmsp_matrix_s *m, int *d_row_offsets, int *d_cols, double *d_vals, hipStream_t st);
@@ -67,6 +75,9 @@ void matrix_compare_device(bmsp_matrix_s *m, int64_t nnz, const int *d_rows, con
 bmsp_matrix_s *build_from_device_csr(int num_rows, int num_cols, int64_t nnz, const int *d_row_offsets, const int *d_cols, const double *d_vals,
                                      int transposed, bmsp_dtype dtype, hipStream_t st);
 void free_matrix(bmsp_matrix_s *m);
+// eager construction of the cached derived structures (bmsp_matrix_prepare)
+void prepare_spmv(bmsp_matrix_s *m, hipStream_t st);
+void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st);
 
 void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st);
 void spmm(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, int k, hipStream_t st);

@@ -504,6 +504,14 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
 
 }  // namespace
 
+void prepare_spmv(bmsp_matrix_s *A, hipStream_t st)
+{
+    if (A->transposed || A->num_block_rows() == 0) return;
+    const size_t es = dtype_size(A->dtype);
+    if ((size_t)A->values_extent() * es >= (1ull << 32) || (size_t)A->num_cols * es >= (1ull << 32)) return;  // block-row kernel: no plan
+    build_plan(A, st);
+}
+
 void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st)
 {
     if (A->transposed) fail(BMSP_ERR_INVALID, "SpMV needs a matrix built with transposed=0");

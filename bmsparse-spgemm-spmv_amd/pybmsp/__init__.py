@@ -26,8 +26,8 @@ SYMBOLS = [
     "bmsp_memcpy_h2d", "bmsp_memcpy_d2h", "bmsp_memcpy_d2d", "bmsp_memset", "bmsp_synchronize", "bmsp_trim_pool",
     "bmsp_event_create", "bmsp_event_record", "bmsp_event_elapsed_ms", "bmsp_event_destroy",
     "bmsp_matrix_from_mtx", "bmsp_matrix_from_coo", "bmsp_matrix_from_coo_device", "bmsp_matrix_from_arrays",
-    "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
-    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmm", "bmsp_spgemm", "bmsp_segsort_u64",
+    "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_prepare", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
+    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmm", "bmsp_spgemm", "bmsp_selftest_mfma_layout", "bmsp_segsort_u64",
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
     "bmsp_csr_spmv", "bmsp_csr_free",
@@ -87,6 +87,7 @@ def lib():
         L.bmsp_matrix_save.argtypes = [vp, C.c_char_p]
         L.bmsp_matrix_load.argtypes = [C.c_char_p, p(vp)]
         L.bmsp_matrix_free.argtypes = [vp]
+        L.bmsp_matrix_prepare.argtypes = [vp, i, vp]
         L.bmsp_matrix_info.argtypes = [vp, p(i), p(i), p(i64), p(i64), p(i), p(i)]
         L.bmsp_matrix_arrays.argtypes = [vp, p(vp), p(vp), p(vp), p(vp)]
         L.bmsp_matrix_block_row_ptr.argtypes = [vp, p(vp), p(i64)]
@@ -99,6 +100,7 @@ def lib():
         L.bmsp_spmv.argtypes = [vp, vp, vp, i, vp]
         L.bmsp_spmm.argtypes = [vp, vp, i64, vp, i64, i, vp]
         L.bmsp_spgemm.argtypes = [vp, vp, p(vp), i, i, i, vp, p(SpgemmStats)]
+        L.bmsp_selftest_mfma_layout.argtypes = [p(i)]
         L.bmsp_segsort_u64.argtypes = [vp, vp, i, i64, vp, i64, vp]
         L.bmsp_partition_rows.argtypes = [vp, vp, i, vp]
         L.bmsp_matrix_row_panel.argtypes = [vp, i64, i64, p(vp)]
@@ -251,6 +253,20 @@ class BmSpMatrix:
         check(lib().bmsp_matrix_from_arrays(int(num_rows), int(num_cols), keys.n, values.n, keys.ptr, bmps.ptr, offsets.ptr, values.ptr, dtype,
                                             int(bool(transposed)), 2, C.byref(h)))
         return BmSpMatrix(h.value, parent=(keys, bmps, offsets, values))
+
+    def prepare(self, what=3, stream=None):
+        """builds the cached sweep plan (1) / block-MAC operand records (2) ahead of the first product."""
+        check(lib().bmsp_matrix_prepare(self.h, int(what), stream))
+        return self
+
+    def clone(self):
+        """an independent device copy of the four arrays (bmsp_matrix_from_arrays, ownership 0)."""
+        i = self.info()
+        k, b, o, v = self.device_arrays()
+        h = C.c_void_p()
+        check(lib().bmsp_matrix_from_arrays(i["num_rows"], i["num_cols"], i["block_num"], i["nnz"], k.ptr, b.ptr, o.ptr, v.ptr, i["dtype"],
+                                            i["transposed"], 0, C.byref(h)))
+        return BmSpMatrix(h.value)
 
     def save(self, path):
         check(lib().bmsp_matrix_save(self.h, os.fsencode(path)))

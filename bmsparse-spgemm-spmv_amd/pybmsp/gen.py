@@ -107,3 +107,77 @@ def spmv_x(n, kind="ones"):
     if kind == "ones":
         return np.ones(n, dtype=np.float32)
     return ((np.arange(n) % 21) - 10).astype(np.float32)
+
+
+# ---- CUSP gallery generators (restated from cusp/gallery/detail/{poisson,stencil,random}.inl) ---------------------------------
+_STENCILS = {
+    # (offsets per grid dimension, first dimension fastest), centre value; poisson.inl:29-118
+    "5pt": ([(0, -1), (-1, 0), (0, 0), (1, 0), (0, 1)], 4.0),
+    "9pt": ([(i, j) for j in (-1, 0, 1) for i in (-1, 0, 1)], 8.0),
+    "7pt": ([(0, 0, -1), (0, -1, 0), (-1, 0, 0), (0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)], 6.0),
+    "27pt": ([(i, j, k) for k in (-1, 0, 1) for j in (-1, 0, 1) for i in (-1, 0, 1)], 26.0),
+}
+
+
+def poisson(kind, *grid):
+    """cusp::gallery::poisson{5,9,7,27}pt on a grid (first dimension fastest, stencil.inl:38-50): row = x + m*(y + n*z),
+    neighbours outside the grid are dropped, off-centre value -1, centre value 4 / 8 / 6 / 26.  Sorted by (row, col)."""
+    pts, centre = _STENCILS[kind]
+    grid = [int(g) for g in grid]
+    assert len(grid) == len(pts[0])
+    n = int(np.prod(grid))
+    idx = np.arange(n, dtype=np.int64)
+    coords, rem = [], idx.copy()
+    for g in grid:
+        coords.append(rem % g)
+        rem //= g
+    strides = np.cumprod([1] + grid[:-1])
+    rows, cols, vals = [], [], []
+    for p in pts:
+        ok = np.ones(n, dtype=bool)
+        off = 0
+        for d, (dx, g) in enumerate(zip(p, grid)):
+            x = coords[d] + dx
+            ok &= (x >= 0) & (x < g)
+            off += int(strides[d]) * dx
+        rows.append(idx[ok])
+        cols.append(idx[ok] + off)
+        vals.append(np.full(int(ok.sum()), centre if all(q == 0 for q in p) else -1.0))
+    r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    o = np.lexsort((c, r))
+    return n, n, r[o].astype(np.int32), c[o].astype(np.int32), v[o]
+
+
+def cusp_random(m, n, num_samples):
+    """cusp::gallery::random (random.inl:30-60): srand(m ^ n ^ samples); rand() % m, rand() % n, value 1; sorted, duplicates
+    dropped.  Uses the C library's rand(), as the reference does (the committed fixtures pin glibc's sequence)."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.srand(ctypes.c_uint(m ^ n ^ num_samples))
+    pairs = set()
+    for _ in range(num_samples):
+        r = libc.rand() % m
+        c = libc.rand() % n
+        pairs.add((r, c))
+    pairs = sorted(pairs)
+    r = np.array([p[0] for p in pairs], dtype=np.int32)
+    c = np.array([p[1] for p in pairs], dtype=np.int32)
+    return m, n, r, c, np.ones(len(pairs))
+
+
+def fem_like(side=47, kind="27pt", window=32, seed=1, values="random"):
+    """structurally faithful stand-in for a 3-D FEM matrix such as 2cubes_sphere (101 492 rows, 16.2 entries per row):
+    the poisson 7pt / 27pt stencil on a side^3 grid (47^3 = 103 823 rows) under a bandwidth-limited random symmetric
+    permutation -- vertex ids are shuffled inside consecutive windows of `window` ids, as a mesh generator's numbering would
+    scatter neighbours -- so tiles are partly filled and block columns irregular instead of the perfect diagonals of the
+    lexicographic grid.  values: "random" U(-1,1) (symmetric pattern, unsymmetric values) or "stencil" (the integer stencil)."""
+    n, _, r, c, v = poisson(kind, side, side, side)
+    ids = np.arange(n, dtype=np.int64)
+    key = (ids // window) * np.int64(1 << 32) + (splitmix64((np.uint64(seed) << np.uint64(40)) + ids.astype(np.uint64)) >> np.uint64(40)).astype(np.int64)
+    perm = np.empty(n, dtype=np.int64)
+    perm[np.argsort(key, kind="stable")] = ids   # old id -> new id, windows stay in place
+    r2, c2 = perm[r], perm[c]
+    if values == "random":
+        v = 2.0 * uniform01((np.uint64(seed + 3) << np.uint64(44)) + (r2.astype(np.uint64) * np.uint64(n) + c2.astype(np.uint64))) - 1.0
+    o = np.lexsort((c2, r2))
+    return n, n, r2[o].astype(np.int32), c2[o].astype(np.int32), v[o]

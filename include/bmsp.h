@@ -114,6 +114,14 @@ int bmsp_matrix_arrays(bmsp_matrix_t m, uint64_t **d_keys, uint64_t **d_bmps, ui
  * (the reference rebuilds a compressed one on every call, src/bmSparse_SPMV.cu:199-206). */
 int bmsp_matrix_block_row_ptr(bmsp_matrix_t m, const uint32_t **d_rowptr, int64_t *num_block_rows);
 
+/* Builds, ahead of the first product, the per-matrix structures the operators derive lazily and cache (none of them is part of
+ * the reference's public state): `what` bit 0 = the SpMV sweep plan (the reference rebuilds its block-row pointer inside every
+ * timed SpMV, src/bmSparse_SPMV.cu:199-206); bit 1 = the packed operand records of the SpGEMM block-MAC (both operand roles).
+ * Idempotent; asynchronous on `stream` except for the scalar read-backs of the plan. */
+#define BMSP_PREPARE_SPMV 1
+#define BMSP_PREPARE_SPGEMM 2
+int bmsp_matrix_prepare(bmsp_matrix_t m, int what, void *stream);
+
 /* bmSpMatrix<T>::generate_coo()  -- src/bmSpMatrix.cu:320-363.  Expands to host COO sorted by (row,col);
  * rows/cols/vals must hold nnz entries.  Unlike the reference it honours the transposed layout. */
 int bmsp_matrix_to_coo_host(bmsp_matrix_t m, int *rows, int *cols, double *vals);
@@ -186,6 +194,12 @@ typedef struct {
  * and concatenated; stats then hold the sums over the panels (stage lines are printed per panel). */
 int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, int verbose,
                 void *stream, bmsp_spgemm_stats *stats);
+
+/* Hardware self test of the operand / result lane layout the K = 32 block-MAC relies on (v_mfma_f32_16x16x32_f16: lane l holds
+ * A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15], D[4*(l>>4)+i][l&15]): one 16x16x32 product of asymmetric small integers against a host
+ * loop.  *mismatches = number of wrong elements (0 on gfx950).  The reference's analogue is the fragment-layout assumption of
+ * multiplyV12..V14 (src/bmSparse_SPGEMM.cu:548-552), which it never checks. */
+int bmsp_selftest_mfma_layout(int *mismatches);
 
 /* bb_segsort<K,T>(keys, vals, n, segs, length)  -- include/bb_segsort-master/bb_segsort.h:35-192,
  * instantiated by the reference with K = uint64_t, T = 16-byte task_list_elem (src/bmSparse_SPGEMM.cu:1010).

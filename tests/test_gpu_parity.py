@@ -337,6 +337,106 @@ def test_spgemm_ragusa_known_answers(oracle, bmsp):
                     assert sorted([i, j, val] for (i, j), val in d.items()) == ka["entries"]
 
 
+def test_mfma_16x16x32_lane_layout(bmsp):
+    """the operand / result lane maps of v_mfma_f32_16x16x32_f16 that blockmac32.hip packs tiles by, checked on the hardware with
+    asymmetric integer operands (a transposed or permuted map cannot pass)."""
+    import ctypes
+    bad = ctypes.c_int(-1)
+    bmsp.check(bmsp.lib().bmsp_selftest_mfma_layout(ctypes.byref(bad)))
+    assert bad.value == 0
+
+
+@pytest.mark.parametrize("b_dense", ["0", "1"])
+@pytest.mark.parametrize("quota", ["64", ""])
+@pytest.mark.parametrize("case", ["rmat", "banded_full", "hub_c_blocks", "rect_ragged", "ragusa"])
+def test_mfma32_block_mac_paths(oracle, bmsp, monkeypatch, case, b_dense, quota):
+    """the K = 32 block-MAC (tc_version 4) with B taken from its dense copy and from the compact values, with the default wave
+    quota and with the smallest one (64 tasks per wave: every window boundary, hub slices crossing quota boundaries, empty
+    wave ranges), against the oracle's exact-product numerics; the r1 kernel (BMSP_MAC_OLD) must agree on the same inputs."""
+    from pybmsp import gen
+    monkeypatch.setenv("BMSP_MAC_B_DENSE", b_dense)
+    if quota:
+        monkeypatch.setenv("BMSP_MAC_QUOTA", quota)
+    exact = False
+    if case == "rmat":
+        n, _, r, c, v = gen.rmat(11, 8)
+        A = Bc = (n, n, r, c, v)
+    elif case == "banded_full":
+        n, _, r, c, v = gen.banded(515, 20)
+        A = Bc = (n, n, r, c, np.round(v * 8) / 8)
+    elif case == "hub_c_blocks":
+        # one dense block-row times one dense block-column: C blocks with hundreds of tasks (W-task slices, carried accumulator)
+        nk = 8 * 300
+        r = np.repeat(np.arange(16), nk); c = np.tile(np.arange(nk), 16)
+        A = (16, nk, r, c, ((r * 7 + c) % 5 - 2).astype(np.float64))
+        Bc = (nk, 16, c, r, ((c * 3 + r) % 7 - 3).astype(np.float64))
+        exact = True
+    elif case == "rect_ragged":
+        _, _, r1, c1, v1 = gen.random_coo(203, 77, 2500, seed=5, integer=True)
+        _, _, r2, c2, v2 = gen.random_coo(77, 331, 3000, seed=6, integer=True)
+        A, Bc = (203, 77, r1, c1, v1), (77, 331, r2, c2, v2)
+        exact = True
+    else:
+        coo = oracle.mtx_read(os.path.join(MTX, "real", "A_matrix.mtx"))
+        A = Bc = (24, 24, coo.rows, coo.cols, coo.vals)
+        exact = True
+    st = check_spgemm(oracle, bmsp, A, Bc, 1, 0, 4, exact_expected=exact)
+    assert st["mac_kernel"] == 4
+    # old and new kernels on the same operands
+    a = bmsp.BmSpMatrix.from_coo(*A, dtype=1)
+    b = bmsp.BmSpMatrix.from_coo(*Bc, transposed=True, dtype=1)
+    new, _ = bmsp.spgemm(a, b, tc_version=4)
+    monkeypatch.setenv("BMSP_MAC_OLD", "1")
+    old, _ = bmsp.spgemm(a, b, tc_version=4)
+    monkeypatch.delenv("BMSP_MAC_OLD")
+    vo, vn = old.host_arrays()[3], new.host_arrays()[3]
+    if exact:
+        np.testing.assert_array_equal(vo, vn)
+    else:
+        np.testing.assert_allclose(vn, vo, rtol=2e-3, atol=1e-5)
+
+
+def _cusp_pairs():
+    g = json.load(open(os.path.join(GOLDEN, "cusp_multiply.json")))
+    return [(p["left"], p["right"]) for p in g["products"]]
+
+
+@pytest.mark.parametrize("pair", _cusp_pairs(), ids=lambda p: "%sx%s" % p)
+def test_spgemm_cusp_known_answers(oracle, bmsp, pair):
+    """cusp/testing/multiply.cu:39-128: every compatible pair of the literal / gallery matrices A..K, expected value = the dense
+    product committed in tests/golden/cusp_multiply.json; fp32 and fp16, every block-MAC version, every sort mode.  Values are
+    small multiples of 0.5 -- exact in fp16 -- so even the matrix-core path must match bit for bit; the oracle's structure and
+    stage counters are checked alongside (check_spgemm)."""
+    g = json.load(open(os.path.join(GOLDEN, "cusp_multiply.json")))
+    L, R = np.asarray(g["matrices"][pair[0]]["dense"], dtype=np.float64), np.asarray(g["matrices"][pair[1]]["dense"], dtype=np.float64)
+    want = np.asarray([p for p in g["products"] if (p["left"], p["right"]) == pair][0]["dense"], dtype=np.float64)
+    r1, c1 = np.nonzero(L)
+    r2, c2 = np.nonzero(R)
+    A_coo = (L.shape[0], L.shape[1], r1.astype(np.int32), c1.astype(np.int32), L[r1, c1])
+    B_coo = (R.shape[0], R.shape[1], r2.astype(np.int32), c2.astype(np.int32), R[r2, c2])
+    for dtype, tcs in ((0, (5,)), (1, (5, 4, 3, 2, 1)), (2, (5,))):
+        for tc in tcs:
+            for mode in (0, 1, 2):
+                check_spgemm(oracle, bmsp, A_coo, B_coo, dtype, mode, tc, exact_expected=True)
+        A = bmsp.BmSpMatrix.from_coo(*A_coo, dtype=dtype)
+        B = bmsp.BmSpMatrix.from_coo(*B_coo, transposed=True, dtype=dtype)
+        Cm, _ = bmsp.spgemm(A, B, tc_version=4 if dtype == 1 else 5)
+        k, b, o, v = Cm.host_arrays()
+        got = np.zeros_like(want)
+        for (i, j), val in util.bmsp_host_to_dok(want.shape[0], want.shape[1], k, b, o, v).items():
+            got[i, j] = val
+        np.testing.assert_array_equal(got, want)
+        # the host CSR path of CSRMatrix::multiply on the same pair
+        if dtype == 0:
+            import scipy.sparse as sp
+            la, ra = sp.csr_matrix(L.astype(np.float32)), sp.csr_matrix(R.astype(np.float32))
+            la.sort_indices(); ra.sort_indices()
+            ca = bmsp.CSRMatrix.from_arrays(L.shape[0], L.shape[1], la.indptr, la.indices, la.data)
+            cb = bmsp.CSRMatrix.from_arrays(R.shape[0], R.shape[1], ra.indptr, ra.indices, ra.data)
+            nr, nc, ro, cc, vv = ca.multiply(cb).arrays()
+            np.testing.assert_array_equal(sp.csr_matrix((vv, cc, ro), shape=(nr, nc)).toarray().astype(np.float64), want)
+
+
 @pytest.mark.parametrize("path", [p for p in util.all_fixture_mtx() if "real_general" not in p])
 @pytest.mark.parametrize("dtype,tc", [(0, 5), (1, 5), (1, 4)])
 def test_spgemm_fixtures_square(oracle, bmsp, path, dtype, tc):
@@ -645,6 +745,30 @@ def test_row_panel_views_fp16_mfma_and_spmv(oracle, bmsp):
     yp = bmsp.spmv(view, x).to_host()
     np.testing.assert_array_equal(yp[lo * 8: hi * 8], y[lo * 8: hi * 8])
     assert not yp[: lo * 8].any() and not yp[hi * 8:].any()
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_row_panel_views_expand_and_compare(bmsp, dtype):
+    """a NON-first panel view (offsets absolute into the parent's values, outputs sized by the view's own nnz) through every
+    expansion entry point: generate_coo (host + device), CSR conversion, compare (host + device)."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(11, 6)
+    v = np.round(v * 8) / 8
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=dtype)
+    nbr = (n + 7) // 8
+    for lo, hi in ((nbr // 3, 2 * nbr // 3), (nbr - 5, nbr), (7, 7)):
+        view = A.row_panel(lo, hi)
+        sel = (r >= lo * 8) & (r < hi * 8)
+        assert view.nnz == int(sel.sum())
+        pr, pc, pv = view.to_coo()
+        np.testing.assert_array_equal(pr, r[sel]); np.testing.assert_array_equal(pc, c[sel]); np.testing.assert_array_equal(pv, v[sel])
+        dr, dc, dv = view.to_coo_device()
+        np.testing.assert_array_equal(dr.to_host(), r[sel]); np.testing.assert_array_equal(dc.to_host(), c[sel]); np.testing.assert_array_equal(dv.to_host(), v[sel])
+        ro, cc, vv = view.to_csr_device()
+        np.testing.assert_array_equal(ro.to_host(), np.searchsorted(r[sel], np.arange(n + 1), side="left").astype(np.int32))
+        np.testing.assert_array_equal(cc.to_host(), c[sel]); np.testing.assert_array_equal(vv.to_host(), v[sel])
+        assert view.compare(r, c, v) == (0.0, 0)
+        assert view.compare_device(bmsp.DeviceArray.from_host(r, np.int32), bmsp.DeviceArray.from_host(c, np.int32), bmsp.DeviceArray.from_host(v, np.float64)) == (0.0, 0)
 
 
 @pytest.mark.parametrize("dtype", [0, 1, 2])

@@ -189,3 +189,49 @@ def test_cusp_literal_spmv_known_answer(oracle):
     np.testing.assert_array_equal(oracle.csr_spmv(A, x, 1), dense @ x)
     M = oracle.bmsp_from_coo(coo, oracle.F32, False)
     np.testing.assert_array_equal(oracle.spmv_f32(M, x), dense @ x)
+
+
+def _cusp_cases():
+    g = json.load(open(os.path.join(GOLDEN, "cusp_multiply.json")))
+    return g, [(p["left"], p["right"]) for p in g["products"]]
+
+
+def _coo_of_dense(d):
+    a = np.asarray(d, dtype=np.float64)
+    r, c = np.nonzero(a)
+    return a.shape[0], a.shape[1], r.astype(np.int32), c.astype(np.int32), a[r, c]
+
+
+@pytest.mark.parametrize("pair", _cusp_cases()[1], ids=lambda p: "%sx%s" % p)
+def test_cusp_multiply_known_answers(oracle, pair):
+    """cusp/testing/multiply.cu:39-128 -- every compatible pair of A..K, dense product as the expected value (the reference
+    test's own method), through BOTH CPU restatements: the CSR Gustavson baseline (csr_spgemm.h:39-157, seq + OpenMP) and the
+    bmSparse pipeline (fp32 V15 order, fp16 rounded- and exact-product).  All values are small multiples of 0.5: exact."""
+    g, _ = _cusp_cases()
+    L, R = g["matrices"][pair[0]], g["matrices"][pair[1]]
+    want = np.asarray([p for p in g["products"] if (p["left"], p["right"]) == pair][0]["dense"], dtype=np.float64)
+    ar, ac, r1, c1, v1 = _coo_of_dense(L["dense"])
+    br, bc, r2, c2, v2 = _coo_of_dense(R["dense"])
+    # CSR baseline: compare dense images
+    A, B = oracle.csr_from_coo(oracle.Coo(ar, ac, r1, c1, v1)), oracle.csr_from_coo(oracle.Coo(br, bc, r2, c2, v2))
+    for th in (1, 4):
+        Cm, _ = oracle.csr_spgemm(A, B, th)
+        got = np.zeros((ar, bc))
+        for i in range(ar):
+            for q in range(Cm.row_offsets[i], Cm.row_offsets[i + 1]):
+                got[i, Cm.cols[q]] += Cm.vals[q]
+        np.testing.assert_array_equal(got, want)
+        if th == 1:  # the sequential pass drops numeric zeros (csr_spgemm.h:135); the OpenMP pass keeps them (omp/.../csr_spgemm.h:139-152)
+            assert not np.any(Cm.vals == 0.0)
+    # bmSparse pipeline: symbolic nnz keeps cancelled entries as explicit zeros (SPGEMM.cu:1085-1107)
+    for dt in (oracle.F32, oracle.F16):
+        a = oracle.bmsp_from_coo(oracle.Coo(ar, ac, r1, c1, v1), dt, False)
+        b = oracle.bmsp_from_coo(oracle.Coo(br, bc, r2, c2, v2), dt, True)
+        for exact in (False, True):
+            Cb, st = oracle.spgemm(a, b, exact_products=exact)
+            d = util.bmsp_host_to_dok(ar, bc, Cb.keys, Cb.bmps, Cb.offsets, Cb.values)
+            got = np.zeros((ar, bc))
+            for (i, j), v in d.items():
+                got[i, j] = v
+            np.testing.assert_array_equal(got, want)
+            assert set(zip(*np.nonzero(want))) <= set(d)
