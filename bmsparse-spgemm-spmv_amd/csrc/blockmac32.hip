@@ -69,11 +69,14 @@ struct Mac32Args {
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
-template <int W, bool B_DENSE>
-__global__ __launch_bounds__(kThreads) void block_mac_mfma32_kernel(Mac32Args g)
+// 4 workgroups per CU (LDS: 4 x 38 KB): the register allocation is held to 128 so that the fourth one fits
+template <int W, bool B_DENSE, int V>
+__global__ __launch_bounds__(kThreads, 4) void block_mac_mfma32_kernel(Mac32Args g)
 {
-    // per wave: W task records (16 B) | W + 1 slots of 256 B (A lines 0-7, B lines 0-7); slot W stays zero
-    constexpr int kUnits = 17 * W + 16;
+    static_assert(W == 32, "the head-flag ballots below are 32 bits wide");
+    // per wave: W records (16 B: task records while staging, C-tile records while storing) | W + 1 slots of 256 B (A lines 0-7,
+    // B lines 0-7; slot W stays zero) | the MFMA schedule: W steps x 8 slot bytes, W step words, W head flags
+    constexpr int kUnits = 17 * W + 16 + (16 * W + 4 * W + 4 * W) / 16;
     __shared__ u32x4_t lds_all[4][kUnits];
     __shared__ uint64_t s_sel[16];
     const int w = wave_id(), lane = lane_id();
@@ -81,18 +84,29 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma32_kernel(Mac32Args g)
     u32x4_t *rec = lds_all[w];
     u32x4_t *tiles = rec + W;
     float *tf = (float *)tiles;
+    u32x4_t *sched = tiles + 16 * (W + 1);                   // [W] per step: 8 x uint16 = byte offset of the slot feeding (tile of the pair, K slot); slot W = dead
+    uint16_t *sched16 = (uint16_t *)sched;
+    uint32_t *dinfo = (uint32_t *)(sched + W);               // [W] bit 0: first step of a pair, bit 1: last; bytes 1, 2: D slots
+    uint32_t *hflag = dinfo + W;                             // [W] 1 = a C tile begins at this task of the window
     if (lane < 16) tiles[16 * W + lane] = u32x4_t{0u, 0u, 0u, 0u};
     __syncthreads();
 
-    const int r = lane & 7, grp = lane >> 3;      // staging: lane group `grp` = one task, line r
+    const int r = lane & 7, grp = lane >> 3;      // staging / storing: lane group `grp` = one task / one C tile, line r
     const int ks = lane >> 4, half_sel = grp & 1;  // MFMA: K slot, which C tile of the pair
     const NibbleLane nl0 = make_nibble_lane(r, 0), nl1 = make_nibble_lane(r, 1);
     const rsrc_t rda = make_rsrc(g.a_dense, g.a_dense_bytes);
     const rsrc_t rdb = make_rsrc(B_DENSE ? (const void *)g.b_dense : (const void *)g.b_vals, B_DENSE ? g.b_dense_bytes : g.b_bytes);
     const rsrc_t rmb = make_rsrc(g.b_meta, g.b_meta_bytes);
 
+    // XCD-aware order: workgroups b and b + 8 share an XCD (round-robin dispatch), so the workgroups of one XCD take a contiguous
+    // eighth of the C tiles and neighbouring block-rows -- which read the same B block-rows -- meet in the same L2
+    uint32_t wg;
+    {
+        const uint32_t G = gridDim.x, q = G / 8, rm = G % 8, x = blockIdx.x % 8;
+        wg = (x < rm ? x * (q + 1) : rm * (q + 1) + (x - rm) * q) + blockIdx.x / 8;
+    }
     // the wave's C-tile range: tiles whose first task falls into [wv * quota, (wv + 1) * quota)
-    const uint32_t wv = blockIdx.x * 4 + w;
+    const uint32_t wv = wg * 4 + w;
     uint32_t rs = g.c_size;
     if (lane < 2) {
         const uint64_t t = (uint64_t)(wv + lane) * g.quota;
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma32_kernel(Mac32Args g)
     }
     uint32_t hub_lo = 0;
     bool in_hub = false;
-    float4_t hub_acc = {0.f, 0.f, 0.f, 0.f};
+    float4_t acc = {0.f, 0.f, 0.f, 0.f};  // lives across windows: a hub tile's slices accumulate into it
 
     while (c < ce) {
         // ---- window: whole C tiles with <= W tasks, or a W-task slice of one hub tile ----
@@ -148,40 +162,78 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma32_kernel(Mac32Args g)
             const uint32_t nt = w_lo + w_n;
             if (lane < W && nt + lane < g.n_tasks) tk_n = g.tasks[nt + lane];
         }
-        // ---- task records: lane-per-task gather of B's block record (compact B only) ----
-        {
-            u32x4_t rc = {0u, 0u, 0u, 0u};
-            if ((uint32_t)lane < w_n) {
-                const uint32_t a = (uint32_t)(tk >> 32), b = (uint32_t)tk;
-                if (B_DENSE) {
-                    rc[0] = b; rc[3] = a;
-                } else {
-                    const u32x4_t m = __builtin_amdgcn_raw_buffer_load_b128(rmb, b << 4, 0, 0);
-                    rc[0] = m[0]; rc[1] = m[1]; rc[2] = m[2] * 2u; rc[3] = a;
-                }
+        // ---- task records: lane-per-task gather of B's block record (compact B only); the request is issued here, the record
+        //      is written once the schedule knows the task's K slot ----
+        u32x4_t rc_me = {0u, 0u, 0u, 0u};
+        if ((uint32_t)lane < w_n) {
+            const uint32_t a = (uint32_t)(tk >> 32), b = (uint32_t)tk;
+            if (B_DENSE) {
+                rc_me[0] = b; rc_me[3] = a;
+            } else {
+                const u32x4_t m = __builtin_amdgcn_raw_buffer_load_b128(rmb, b << 4, 0, 0);
+                rc_me[0] = m[0]; rc_me[1] = m[1]; rc_me[2] = m[2] * 2u; rc_me[3] = a;
             }
-            if (lane < W) rec[lane] = rc;
+        }
+        if (lane < W) {
+            sched[lane] = u32x4_t{0x00010001u * (256u * W), 0x00010001u * (256u * W), 0x00010001u * (256u * W), 0x00010001u * (256u * W)};  // every K slot dead
+            dinfo[lane] = 0u;
+            hflag[lane] = 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- the MFMA schedule of the window, lane-parallel.  Tile lanes: steps of their pair = max of the two task counts / 4,
+        //      exclusive sum over pairs = first step of the pair.  Task lanes: tile and rank inside it from the head-flag ballot;
+        //      the task's slot number goes into byte (tile & 1) * 4 + rank % 4 of step first(pair) + rank / 4. ----
+        uint32_t n_steps;
+        {
+            const uint32_t tb_next = (uint32_t)__shfl_down((int)tbv, 1, kWave);
+            const bool is_tile = (uint32_t)lane < ntiles;
+            const uint32_t cnt = !is_tile ? 0u : (n > 0 ? tb_next - tbv : w_n);
+            const uint32_t slot_me = n > 0 ? tbv - w_lo : 0u;  // slot of the tile's first task
+            const uint32_t cnt_o = (uint32_t)__shfl_xor((int)cnt, 1, kWave), slot_o = (uint32_t)__shfl_xor((int)slot_me, 1, kWave);
+            const uint32_t steps = (max(cnt, cnt_o) + 3) / 4;
+            const uint32_t mine = (lane & 1) ? 0u : steps;
+            const uint32_t incl = wave_inclusive_sum(mine);
+            n_steps = rl(incl, 63);
+            const uint32_t base = incl - mine;  // even lane: first step of my pair; odd lane: one past my pair's last step
+            if (is_tile) hflag[slot_me] = 1u;
+            if (is_tile && !(lane & 1)) {
+                // the pair's last step carries the D slots (bit 1); a single-step pair also sets bit 0 (no accumulator needed).
+                // A hub slice that is not the last keeps its sum in registers: no D word
+                const uint32_t dsl = (slot_me << 8) | ((cnt_o ? slot_o : 0xffu) << 16);
+                if (n > 0 || last) dinfo[base + steps - 1] = 2u | dsl | ((steps == 1 && n > 0) ? 1u : 0u);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t heads = (uint32_t)__ballot((uint32_t)lane < w_n && hflag[lane & (W - 1)] != 0u);
+            const uint32_t le = (heads & (0xffffffffu >> (31 - (lane & 31)))) | 1u;  // task 0 always begins a tile
+            const uint32_t j = (uint32_t)__builtin_popcount(le) - 1u;
+            const uint32_t idx = (uint32_t)(lane & 31) - (31u - (uint32_t)__builtin_clz(le));
+            const uint32_t pbase = (uint32_t)__shfl((int)base, (int)(j & ~1u), kWave);  // every lane takes part in the shuffle
+            if ((uint32_t)lane < w_n) sched16[(pbase + (idx >> 2)) * 8u + (j & 1u) * 4u + (idx & 3u)] = (uint16_t)(lane * 256);
+            // bank swizzle: tasks in odd K slots keep their A lines in the upper half of the slot (B lines in the lower), so the
+            // 16 lanes a ds_read_b128 serves together -- lines 0-3 / 4-7 of K slots k and k+1 -- fall on 16 different 16-byte banks
+            if (!(V & 2)) rc_me[3] |= (idx & 1u) << 31;
+            if (lane < W) rec[lane] = rc_me;
         }
         __builtin_amdgcn_wave_barrier();
         // ---- staging: 8 lanes per task, one 16-byte line each; all requests of the window first, then the decode ----
-        {
+        if (!(V & 16)) {
             constexpr int U = W / 8;
             u32x4_t av[U];
             u32x4_t bd[U];        // dense B line
             u32x3_t bq0[U], bq1[U];  // compact B: the two nibble windows
-            uint32_t nib0[U], nib1[U], ad0[U], ad1[U];
+            uint32_t nib0[U], nib1[U], ad0[U], ad1[U], swz[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t t = (uint32_t)(8 * u + grp);
-                const bool live = t < w_n;
                 const u32x4_t rc = rec[t];
-                av[u] = __builtin_amdgcn_raw_buffer_load_b128(rda, live ? (rc[3] << 7) + (uint32_t)(r * 16) : kOob, 0, 0);
+                swz[u] = (rc[3] >> 31) * 8u;
+                av[u] = __builtin_amdgcn_raw_buffer_load_b128(rda, (rc[3] << 7) + (uint32_t)(r * 16), 0, 0);  // dead tasks: record 0, unused (bit 31 shifts out)
                 if (B_DENSE) {
-                    bd[u] = __builtin_amdgcn_raw_buffer_load_b128(rdb, live ? (rc[0] << 7) + (uint32_t)(r * 16) : kOob, 0, 0);
+                    bd[u] = __builtin_amdgcn_raw_buffer_load_b128(rdb, (rc[0] << 7) + (uint32_t)(r * 16), 0, 0);
                 } else {
                     const uint32_t lo = rc[0], hi = rc[1];
-                    nib0[u] = live ? ((nl0.use_hi ? hi : lo) >> nl0.shift) & 0xfu : 0u;
-                    nib1[u] = live ? ((nl1.use_hi ? hi : lo) >> nl1.shift) & 0xfu : 0u;
+                    nib0[u] = ((nl0.use_hi ? hi : lo) >> nl0.shift) & 0xfu;  // dead tasks carry an all-zero record: no nibble, no request
+                    nib1[u] = ((nl1.use_hi ? hi : lo) >> nl1.shift) & 0xfu;
                     ad0[u] = rc[2] + 2u * ((uint32_t)__builtin_popcount(hi & nl0.hi_mask) + (uint32_t)__builtin_popcount(lo & nl0.lo_mask));
                     ad1[u] = ad0[u] + 2u * (uint32_t)__builtin_popcount(nib0[u]);
                     bq0[u] = __builtin_amdgcn_raw_buffer_load_b96(rdb, nib0[u] ? (ad0[u] & ~3u) : kOob, 0, 0);
@@ -205,61 +257,68 @@ __global__ __launch_bounds__(kThreads) void block_mac_mfma32_kernel(Mac32Args g)
                     bl[3] = __builtin_amdgcn_perm(b23, b01, (uint32_t)(s1 >> 32));
                 }
                 if (t < w_n) {
-                    tiles[16 * t + r] = av[u];
-                    tiles[16 * t + 8 + r] = bl;
+                    tiles[16 * t + (r ^ swz[u])] = av[u];
+                    tiles[16 * t + (r ^ swz[u] ^ 8u)] = bl;
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- MFMA: pairs of C tiles, four tasks of each per instruction ----
-        const uint32_t pairs = (ntiles + 1) / 2;
-        for (uint32_t p = 0; p < pairs; p++) {
-            const uint32_t j0 = 2 * p, j1 = 2 * p + 1;
-            uint32_t b0, e0, e1;
-            if (n > 0) {
-                b0 = rl(tbv, j0); e0 = rl(tbv, j0 + 1);
-                e1 = j1 < ntiles ? rl(tbv, j1 + 1) : e0;
-            } else {
-                b0 = w_lo; e0 = w_lo + w_n; e1 = e0;
-            }
-            const uint32_t n0 = e0 - b0, n1 = e1 - e0;
-            const uint32_t steps = (max(n0, n1) + 3) / 4;
-            const uint32_t my_n = half_sel ? n1 : n0, my_b = (half_sel ? e0 : b0) - w_lo;
-            float4_t acc = (n == 0 && !first) ? hub_acc : float4_t{0.f, 0.f, 0.f, 0.f};
-            for (uint32_t s = 0; s < steps; s++) {
-                const uint32_t idx = 4 * s + (uint32_t)ks;
-                const uint32_t slot = idx < my_n ? my_b + idx : (uint32_t)W;
-                const half8_t fa = __builtin_bit_cast(half8_t, tiles[16 * slot + r]);
-                const half8_t fb = __builtin_bit_cast(half8_t, tiles[16 * slot + 8 + r]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
-            }
-            if (n == 0 && !last) {
-                hub_acc = acc;
-            } else {
-                // D[4*(lane>>4) + i][lane & 15]: tile 0 = rows/cols 0-7, tile 1 = rows/cols 8-15.  Column-major into the slot
-                // of the tile's own first task: float index (col & 7) * 8 + row
-                const int dt = lane >> 5;  // which tile this lane's rows belong to
-                const bool useful = dt == ((lane >> 3) & 1) && (dt == 0 || j1 < ntiles);
-                if (useful) {
-                    const uint32_t slot = (dt ? e0 : b0) - w_lo;
-                    tiles[16 * slot + 2 * (lane & 7) + ((lane >> 4) & 1)] = __builtin_bit_cast(u32x4_t, acc);
+        // ---- C-tile records for the store phase (the task records are dead now): {bitmap, first value inside the window, slot} ----
+        const uint32_t off0 = rl((uint32_t)coff, 0);
+        if ((uint32_t)lane < ntiles)
+            rec[lane] = u32x4_t{(uint32_t)cbmp, (uint32_t)(cbmp >> 32), (uint32_t)coff - off0, n > 0 ? tbv - w_lo : 0u};
+        // ---- MFMA steps ----
+        {
+            const char *tbytes = (const char *)tiles;
+            const uint16_t *sp = sched16 + (half_sel * 4 + ks);
+            const uint32_t lofs = (uint32_t)(r * 16) ^ ((V & 2) ? 0u : (uint32_t)((ks & 1) * 128));  // A line of this lane's K slot (B line: ^ 128)
+            const int dt = lane >> 5;
+            const bool d_lane = dt == ((lane >> 3) & 1);
+            float *dbase = tf + 32 * ((lane >> 4) & 1) + (lane & 7);
+            for (uint32_t q = 0; q < ((V & 8) ? 0u : n_steps); q++, sp += 8) {
+                const uint32_t di = (uint32_t)__builtin_amdgcn_readfirstlane((int)dinfo[q]);
+                const char *src = tbytes + (uint32_t)*sp;
+                const half8_t fa = __builtin_bit_cast(half8_t, *(const u32x4_t *)(src + lofs));
+                const half8_t fb = __builtin_bit_cast(half8_t, *(const u32x4_t *)(src + (lofs ^ 128u)));
+                // D[4*(lane>>4) + i][lane & 15]: tile 0 = rows/cols 0-7, tile 1 = rows/cols 8-15.  Row-major into the slot of the
+                // tile's own first task (its operand lines are consumed): float index row * 8 + col
+                const uint32_t dslot = (di >> (dt ? 16 : 8)) & 0xffu;
+                if (!(V & 1) && (di & 3u) == 3u) {  // the whole pair in one step: no accumulator
+                    const float4_t d4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, float4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    if (d_lane && dslot != 0xffu) {
+                        float *d = dbase + 64 * dslot;
+                        d[0] = d4[0]; d[8] = d4[1]; d[16] = d4[2]; d[24] = d4[3];
+                    }
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
+                    if (di & 2u) {
+                        if (d_lane && dslot != 0xffu) {
+                            float *d = dbase + 64 * dslot;
+                            d[0] = acc[0]; d[8] = acc[1]; d[16] = acc[2]; d[24] = acc[3];
+                        }
+                        acc = float4_t{0.f, 0.f, 0.f, 0.f};  // the next pair (or hub tile) starts from zero
+                    }
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- compaction by the C bitmaps, in place, and the coalesced store of the window's values ----
-        if (last) {
-            const uint32_t off0 = rl((uint32_t)coff, 0);
-            for (uint32_t j = 0; j < ntiles; j++) {
-                const uint32_t blo = rl((uint32_t)cbmp, j), bhi = rl((uint32_t)(cbmp >> 32), j);
-                const uint32_t slot = n > 0 ? rl(tbv, j) - w_lo : 0u;
-                const uint32_t o = rl((uint32_t)coff, j) - off0;
-                // position `lane` is bit 63-lane of the bitmap = bit `lane` of its reversal
-                const uint32_t rlo = __builtin_bitreverse32(bhi), rhi = __builtin_bitreverse32(blo);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(rhi, __builtin_amdgcn_mbcnt_lo(rlo, 0u));
-                const float v = tf[64 * slot + (uint32_t)((lane & 7) * 8 + (lane >> 3))];
+        // ---- compaction by the C bitmaps: 8 lanes per C tile, lane = tile row; rows are read whole before any compacted value
+        //      is written (the compacted run [0, total) grows over the D tiles it has consumed), then one coalesced store ----
+        if (last && !(V & 4)) {
+            for (uint32_t q = 0; q < ntiles; q += 8) {
+                const uint32_t j = q + (uint32_t)grp;
+                const bool on = j < ntiles;
+                const u32x4_t rc = rec[on ? j : 0u];
+                const uint32_t lo = rc[0], hi = rc[1];
+                const uint32_t byte = on ? ((nl0.use_hi ? hi : lo) >> (nl0.shift - 4u)) & 0xffu : 0u;
+                uint32_t dst = rc[2] + (uint32_t)__builtin_popcount(hi & nl0.hi_mask) + (uint32_t)__builtin_popcount(lo & nl0.lo_mask);
+                const float4_t v0 = *(const float4_t *)(tf + 64 * rc[3] + 8 * r), v1 = *(const float4_t *)(tf + 64 * rc[3] + 8 * r + 4);
                 __builtin_amdgcn_wave_barrier();
-                if (((lane < 32 ? rlo : rhi) >> (lane & 31)) & 1u) tf[o + rank] = v;
+                const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int cc = 0; cc < 8; cc++) {
+                    if (byte & (0x80u >> cc)) { tf[dst] = vv[cc]; dst++; }
+                }
                 __builtin_amdgcn_wave_barrier();
             }
             const uint32_t total = rl((uint32_t)coff, ntiles) - off0;
@@ -308,13 +367,18 @@ bool mac_mfma32_supported(const bmsp_matrix_s *A, const bmsp_matrix_s *B)
     return A->dtype == BMSP_F16 && A->block_num < (1ll << 25) && B->block_num < (1ll << 25) && (uint64_t)B->values_extent() * 2 + 16 < (1ull << 32);
 }
 
-// which operand form B takes: dense copy when its tiles are mostly full (compact = 16-byte record + 2 B per value) or when its
-// value array is borrowed without the read slack the 12-byte nibble loads need
+// which operand form B takes.  Measured (block-MAC log): the dense copy wins on every generator case -- the kernel is bound
+// by instruction issue and LDS traffic, not by bytes, and the dense line needs no block record and no nibble decode (cage-like
+// 421 vs 468 us, R-MAT 2^16 2.58 vs 2.91 ms, full tiles 72 vs 84 us) -- at 128 B per block of extra memory and ~2x the L2 miss
+// traffic.  So: dense unless the copy would be large (> 4 GiB) and the tiles are sparse, or BMSP_MAC_B_DENSE says otherwise;
+// always dense when the value array is borrowed without the read slack the 12-byte nibble loads need.
 bool mac_mfma32_b_dense(const bmsp_matrix_s *B)
 {
     const char *force = getenv("BMSP_MAC_B_DENSE");  // experiment / test switch (read per call)
     if (force) return force[0] == '1';
-    return !pool_owns(B->values) || (B->block_num && (double)B->nnz / (double)B->block_num >= 32.0);
+    if (!pool_owns(B->values)) return true;
+    const bool full_tiles = B->block_num && (double)B->nnz / (double)B->block_num >= 32.0;
+    return full_tiles || (uint64_t)B->block_num * 128ull <= (4ull << 30);
 }
 
 void launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *task_begin, const uint32_t *c_of_wave, bmsp_matrix_s *A,
@@ -341,8 +405,20 @@ void launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *
     const uint64_t waves = (n_tasks + quota - 1) / quota;
     const uint32_t grid = (uint32_t)((waves + 3) / 4);
     g.quota = (uint32_t)quota;
-    if (b_dense) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, true>), dim3(grid), dim3(kThreads), 0, st, g);
-    else hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false>), dim3(grid), dim3(kThreads), 0, st, g);
+    if (const char *ab = getenv("BMSP_MAC_ABLATE")) {  // timing-only builds: a zero-size descriptor drops every load through it
+        const int m = atoi(ab);
+        if (m & 1) g.a_dense_bytes = 0;
+        if (m & 2) { g.b_bytes = 0; g.b_dense_bytes = 0; }
+        if (m & 4) g.b_meta_bytes = 0;
+    }
+    const char *venv = getenv("BMSP_MAC_VARIANT");  // timing experiments: 4 = no store phase, 8 = no MFMA loop, 16 = no staging (wrong results)
+    const int v = venv ? atoi(venv) : 0;
+    if (b_dense) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, true, 0>), dim3(grid), dim3(kThreads), 0, st, g);
+    else if (v == 4) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 4>), dim3(grid), dim3(kThreads), 0, st, g);
+    else if (v == 8) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 8>), dim3(grid), dim3(kThreads), 0, st, g);
+    else if (v == 16) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 16>), dim3(grid), dim3(kThreads), 0, st, g);
+    else if (v == 28) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 28>), dim3(grid), dim3(kThreads), 0, st, g);
+    else hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 0>), dim3(grid), dim3(kThreads), 0, st, g);
     BMSP_CHECK_LAUNCH();
 }
 
