@@ -470,6 +470,104 @@ __global__ __launch_bounds__(kThreads) void spmv_blockrow_kernel(const uint32_t 
     if (g == 0 && row < num_rows) y[row] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// row-group kernel (variant 3): matrices whose tiles are mostly dense (FEM / banded)
+// ---------------------------------------------------------------------------------------------------------
+// The sweep above is built for hyper-sparse tiles (a lane per TILE).  When a tile holds tens of values the bytes are in the value
+// array, and the job is to stream it with 16-byte loads: here 16 lanes own one block-row (4 block-rows per wave) and walk its
+// tiles; lane j of the group takes tile positions 4j .. 4j+3 (half a tile row): ONE 16-byte load of the <= 4 consecutive stored
+// values behind rank(4j) -- the whole wave moves 1 KB of values per instruction when tiles are full -- against one 16-byte load
+// of the four x entries (block column cached in L1/L2: neighbouring block-rows of a banded matrix read the same x lines).
+// Partly filled nibbles are expanded with three selects; sums stay in registers for the whole block-row (no LDS, no atomics:
+// y is bit-reproducible), the two half-rows meet in one DPP add, 8 lanes store the 8 rows.
+template <typename T, int U>
+__global__ __launch_bounds__(kThreads) void spmv_rowgroup_kernel(const uint32_t *__restrict__ rowptr, const uint64_t *__restrict__ keys,
+                                                                 const uint64_t *__restrict__ bmps, const uint64_t *__restrict__ offsets,
+                                                                 const T *__restrict__ values, const T *__restrict__ x,
+                                                                 typename Acc<T>::type *__restrict__ y, uint32_t num_rows, uint32_t num_cols,
+                                                                 uint32_t nbr, uint32_t values_bytes, uint32_t passes)
+{
+    using A = typename Acc<T>::type;
+    const int lane = lane_id(), j = lane & 15, g = lane >> 4;
+    const uint32_t wv = blockIdx.x * 4 + wave_id();
+    const rsrc_t rv = make_rsrc(values, values_bytes), rx = make_rsrc(x, num_cols * (uint32_t)sizeof(T));
+    const uint32_t xlane = (uint32_t)((j & 1) * 4);        // first of this lane's four tile columns
+    const uint32_t bshift = (uint32_t)(60 - 4 * j) & 31u;   // nibble of positions 4j .. 4j+3 inside its bitmap word
+    const bool in_hi = j < 8;
+    const uint32_t hi_mask = j >= 8 ? 0xffffffffu : (j == 0 ? 0u : 0xffffffffu << (32 - 4 * j));  // bitmap bits of positions < 4j
+    const uint32_t lo_mask = j > 8 ? 0xffffffffu << (64 - 4 * j) : 0u;
+    const bool ragged_x = (num_cols & 3u) != 0u;
+    for (uint32_t p = 0; p < passes; p++) {
+        const uint32_t br = (wv * passes + p) * 4u + (uint32_t)g;
+        if ((wv * passes + p) * 4u >= nbr) break;  // wave-uniform
+        const bool valid = br < nbr;
+        uint32_t t = valid ? rowptr[br] : 0u;
+        const uint32_t t1 = valid ? rowptr[br + 1] : 0u;
+        A acc = 0;
+        while (__any(t < t1)) {
+            uint32_t blo[U], bhi[U], col[U], off[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool on = t + u < t1;
+                const uint64_t bm = on ? bmps[t + u] : 0ull;
+                blo[u] = (uint32_t)bm; bhi[u] = (uint32_t)(bm >> 32);
+                col[u] = on ? (uint32_t)keys[t + u] : 0u;
+                off[u] = on ? (uint32_t)offsets[t + u] : 0u;
+            }
+            A av[U][4], xv[U][4];
+            uint32_t nib[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                nib[u] = ((in_hi ? bhi[u] : blo[u]) >> bshift) & 0xfu;
+                const uint32_t rank = (uint32_t)__builtin_popcount(bhi[u] & hi_mask) + (uint32_t)__builtin_popcount(blo[u] & lo_mask);
+                const uint32_t vaddr = (off[u] + rank) * (uint32_t)sizeof(T);
+                if (sizeof(T) == 2) {
+                    // halves start at any even byte: fetch the enclosing dwords and funnel-shift the odd leading half away
+                    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const u32x3 d = __builtin_amdgcn_raw_buffer_load_b96(rv, nib[u] ? (vaddr & ~3u) : kOob, 0, 0);
+                    const uint32_t sh = (vaddr & 2u) * 8u;
+                    const h2 p0 = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(d[1], d[0], sh)), p1 = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(d[2], d[1], sh));
+                    av[u][0] = (A)p0[0]; av[u][1] = (A)p0[1]; av[u][2] = (A)p1[0]; av[u][3] = (A)p1[1];
+                } else {
+                    Buf4<T>::ld(rv, nib[u] ? vaddr : kOob, av[u]);
+                }
+                const uint32_t xc = col[u] * 8u + xlane;
+                if (ragged_x && xc + 4u > num_cols) {  // a 16-byte load that leaves x reads as zero altogether: last block column only
+#pragma unroll
+                    for (int q = 0; q < 4; q++) xv[u][q] = (A)Buf<T>::ld(rx, nib[u] && xc + q < num_cols ? (xc + q) * (uint32_t)sizeof(T) : kOob);
+                } else {
+                    Buf4<T>::ld(rx, nib[u] ? xc * (uint32_t)sizeof(T) : kOob, xv[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t n = nib[u];
+                A e0, e1, e2, e3;
+                if (__all(n == 0xfu || n == 0u)) {  // full (or absent) nibbles everywhere: values already sit at their positions
+                    e0 = av[u][0]; e1 = av[u][1]; e2 = av[u][2]; e3 = av[u][3];
+                    if (n == 0u) { e0 = e1 = e2 = e3 = A(0); }
+                } else {
+                    // stored values of the nibble are consecutive: position q holds value number popc(bits before q)
+                    const bool b0 = n & 8u, b1 = n & 4u, b2 = n & 2u, b3 = n & 1u;
+                    const uint32_t i2 = (uint32_t)b0 + (uint32_t)b1, i3 = i2 + (uint32_t)b2;
+                    e0 = b0 ? av[u][0] : A(0);
+                    e1 = b1 ? (b0 ? av[u][1] : av[u][0]) : A(0);
+                    e2 = b2 ? (i2 == 0 ? av[u][0] : (i2 == 1 ? av[u][1] : av[u][2])) : A(0);
+                    e3 = b3 ? (i3 == 0 ? av[u][0] : (i3 == 1 ? av[u][1] : (i3 == 2 ? av[u][2] : av[u][3]))) : A(0);
+                }
+                acc += e0 * xv[u][0] + e1 * xv[u][1] + e2 * xv[u][2] + e3 * xv[u][3];
+            }
+            t += U;
+        }
+        // lanes 2r and 2r+1 hold the two halves of tile row r
+        if (sizeof(A) == 4) acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)acc), 0xB1, 0xf, 0xf, false));  // quad_perm 1,0,3,2
+        else acc += __shfl_xor(acc, 1, kWave);
+        const uint32_t row = br * 8u + (uint32_t)(j >> 1);
+        if (valid && !(j & 1) && row < num_rows) y[row] = acc;
+    }
+}
+
 template <typename T>
 void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st)
 {
@@ -491,6 +589,20 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
                            (uint32_t)A->num_cols, nbr);
     } else {
         build_plan(A, st);
+        // dense tiles and no hub block-row: the row-group kernel streams the value array with 16-byte loads (variant 3); the 16-byte
+        // value loads may run 12 bytes past the last stored value: arrays from this library's allocator carry that slack
+        const bool dense_tiles = A->block_num > 0 && A->nnz >= 16 * A->block_num;
+        if ((variant == 3 || (variant == BMSP_SPMV_DEFAULT && dense_tiles && A->spmv_plan_long == 0 && !getenv("BMSP_SPMV_NO_ROWGROUP"))) && pool_owns(A->values)) {
+            constexpr int U = 3;
+            const uint32_t groups = (nbr + 3) / 4;
+            const uint32_t passes = groups > 32768 ? 2u : 1u;
+            const uint32_t waves = (groups + passes - 1) / passes;
+            hipLaunchKernelGGL((spmv_rowgroup_kernel<T, U>), dim3((waves + 3) / 4), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps, A->offsets,
+                               (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows, (uint32_t)A->num_cols, nbr,
+                               (uint32_t)((size_t)A->values_extent() * sizeof(T)) + 16u, passes);
+            BMSP_CHECK_LAUNCH();
+            return;
+        }
         const uint32_t n_items = (uint32_t)A->spmv_num_chunks;
         char *mem = (char *)A->spmv_chunks;
         auto kern = A->spmv_full_tiles * 4 >= A->block_num ? spmv_sweep_kernel<T, true> : spmv_sweep_kernel<T, false>;
@@ -516,7 +628,7 @@ void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st)
 {
     if (A->transposed) fail(BMSP_ERR_INVALID, "SpMV needs a matrix built with transposed=0");
     if (!v || !u) fail(BMSP_ERR_INVALID, "null vector");
-    if (variant < 0 || variant > 2) fail(BMSP_ERR_INVALID, "unknown SpMV variant %d", variant);
+    if (variant < 0 || variant > 3) fail(BMSP_ERR_INVALID, "unknown SpMV variant %d", variant);
     ensure_rowptr(A, st);
     switch (A->dtype) {
     case BMSP_F32: launch<float>(A, v, u, variant, st); break;
