@@ -33,6 +33,7 @@
 #include "spmv_plan.h"
 #include "prims.hip.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace bmsp {
 namespace {
@@ -262,9 +263,41 @@ __device__ __forceinline__ uint64_t peel_tile(uint64_t bm, uint32_t voff, uint32
     return bm;
 }
 
+// the same in two steps, so that the requests of BOTH tiles of a lane can be in flight before the first LDS add
+template <typename T, typename A, int N>
+struct Peeled {
+    A a[N], xv[N];
+    uint32_t pr[N];
+    bool has[N];
+    uint64_t rest;
+};
+template <typename T, typename A, int N>
+__device__ __forceinline__ Peeled<T, A, N> peel_issue(uint64_t bm, uint32_t voff, uint32_t xbase, rsrc_t rv, rsrc_t rx)
+{
+    Peeled<T, A, N> q;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        q.has[j] = bm != 0;
+        const uint32_t p = (uint32_t)__clzll((long long)bm) & 63u;
+        bm &= ~(0x8000000000000000ull >> p);
+        q.pr[j] = p >> 3;
+        q.a[j] = Buf<T>::ld(rv, q.has[j] ? voff + (uint32_t)(j * sizeof(T)) : kOob);
+        q.xv[j] = Buf<T>::ld(rx, q.has[j] ? xbase + (p & 7u) * (uint32_t)sizeof(T) : kOob);
+    }
+    q.rest = bm;
+    return q;
+}
+template <typename T, typename A, int N>
+__device__ __forceinline__ void peel_commit(const Peeled<T, A, N> &q, A *__restrict__ trow)
+{
+#pragma unroll
+    for (int j = 0; j < N; j++)
+        if (q.has[j]) lds_add(trow + q.pr[j], q.a[j] * q.xv[j]);
+}
+
 // FULL: matrices whose plan counted many full tiles (FEM-like) get the variant with the 16-byte-per-lane full-tile pass; the
 // graph-like default keeps the leaner code (the extra pass costs the webbase-like case 7 % even when it never runs)
-template <typename T, bool FULL>
+template <typename T, bool FULL, bool NT, bool PERSIST = false>
 __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *__restrict__ items, uint32_t num_items,
                                                               const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bmps,
                                                               const uint64_t *__restrict__ offsets, const T *__restrict__ values,
@@ -280,16 +313,16 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
     __shared__ uint32_t d_off_all[4][kDenseCap], d_xb_all[4][kDenseCap], d_tb_all[4][kDenseCap];
     __shared__ uint32_t f_off_all[4][kDenseCap], f_xb_all[4][kDenseCap], f_tb_all[4][kDenseCap];
     const int w = wave_id(), lane = lane_id();
-    const uint32_t item_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
-    if (item_id >= num_items) return;
     A *tile = tile_all[w];
     uint64_t *l_bmp = l_bmp_all[w], *d_bmp = d_bmp_all[w];
     uint32_t *l_off = l_off_all[w], *l_xb = l_xb_all[w], *l_tb = l_tb_all[w];
     uint32_t *d_off = d_off_all[w], *d_xb = d_xb_all[w], *d_tb = d_tb_all[w];
     uint32_t *f_off = f_off_all[w], *f_xb = f_xb_all[w], *f_tb = f_tb_all[w];
-    const SweepItem it = items[item_id];
     const rsrc_t rv = make_rsrc(values, values_bytes), rx = make_rsrc(x, num_cols * (uint32_t)sizeof(T));
     const uint64_t lt = lanemask_lt();
+    // PERSIST: the grid is sized to the chip and every wave walks items with the grid stride (no relaunch gaps)
+    for (uint32_t item_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w); item_id < num_items; item_id += PERSIST ? gridDim.x * 4 : num_items) {
+    const SweepItem it = items[item_id];
     tile[lane] = A(0);
     tile[64 + lane] = A(0);
     uint32_t n_left = 0;  // wave-uniform fill of the leftover queue
@@ -299,12 +332,21 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
         // lane-per-tile: three coalesced streams, two tiles per lane
         const uint32_t b0 = base + lane, b1 = base + 64 + lane;
         uint64_t bm0 = 0, bm1 = 0, k0 = (uint64_t)it.row_begin << 32, k1 = k0, o0 = 0, o1 = 0;
-        if (b0 < it.blk_end) { bm0 = bmps[b0]; k0 = keys[b0]; o0 = offsets[b0]; }
-        if (b1 < it.blk_end) { bm1 = bmps[b1]; k1 = keys[b1]; o1 = offsets[b1]; }
+        if (NT) {  // streamed once: non-temporal, so that the tile words do not push x out of the L2
+            if (b0 < it.blk_end) { bm0 = __builtin_nontemporal_load(bmps + b0); k0 = __builtin_nontemporal_load(keys + b0); o0 = __builtin_nontemporal_load(offsets + b0); }
+            if (b1 < it.blk_end) { bm1 = __builtin_nontemporal_load(bmps + b1); k1 = __builtin_nontemporal_load(keys + b1); o1 = __builtin_nontemporal_load(offsets + b1); }
+        } else {
+            if (b0 < it.blk_end) { bm0 = bmps[b0]; k0 = keys[b0]; o0 = offsets[b0]; }
+            if (b1 < it.blk_end) { bm1 = bmps[b1]; k1 = keys[b1]; o1 = offsets[b1]; }
+        }
         const uint32_t x0 = key_col(k0) * 8u * (uint32_t)sizeof(T), x1 = key_col(k1) * 8u * (uint32_t)sizeof(T);
         const uint32_t tb0 = (key_row(k0) - it.row_begin) * 8u, tb1 = (key_row(k1) - it.row_begin) * 8u;
         const uint32_t vo0 = (uint32_t)o0 * (uint32_t)sizeof(T), vo1 = (uint32_t)o1 * (uint32_t)sizeof(T);
-        // the two tiles of a lane are handled one after the other so that the queues never hold more than 64 new entries
+        // the inline element requests of both tiles go out together (one memory round trip for the pair, not two)
+        const bool sp0 = !(FULL && bm0 == ~0ull) && __popcll(bm0) <= kSparseMax, sp1 = !(FULL && bm1 == ~0ull) && __popcll(bm1) <= kSparseMax;
+        const Peeled<T, A, kInlineSlots> pe0 = peel_issue<T, A, kInlineSlots>(sp0 ? bm0 : 0ull, vo0, x0, rv, rx);
+        const Peeled<T, A, kInlineSlots> pe1 = peel_issue<T, A, kInlineSlots>(sp1 ? bm1 : 0ull, vo1, x1, rv, rx);
+        // the two tiles of a lane are queued one after the other so that the queues never hold more than 64 new entries
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint64_t bm = h ? bm1 : bm0;
@@ -326,7 +368,8 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
                 d_bmp[s] = bm; d_off[s] = vo; d_xb[s] = xb; d_tb[s] = tb;
             }
             // every sparse tile: its first kInlineSlots stored values right here (covers most tiles of a graph matrix entirely)
-            const uint64_t rest = peel_tile<T, A, kInlineSlots>((dense || full) ? 0ull : bm, vo, xb, tile + tb, rv, rx);
+            peel_commit<T, A, kInlineSlots>(h ? pe1 : pe0, tile + tb);
+            const uint64_t rest = h ? pe1.rest : pe0.rest;
             // tiles with more values wait in the leftover queue until 64 of them make a full wave
             const uint64_t lm = __ballot(rest != 0);
             if (rest) {
@@ -396,7 +439,8 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
         const uint32_t n_out = (it.row_end - it.row_begin) * 8u, out0 = it.row_begin * 8u;
         for (uint32_t e = lane; e < n_out; e += 64)
             if (out0 + e < num_rows) y[out0 + e] = tile[e];
-        return;
+        __builtin_amdgcn_wave_barrier();
+        continue;
     }
     // long row: park the partial sums, the last arriver folds them.  Write-through (sc1) stores + drained vmcnt +
     // agent-scope counter add; the wave whose add comes last reads every slot with sc1 loads (MI355X_MICROARCH.md
@@ -407,7 +451,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
     uint32_t ticket = 0;
     if (lane == 0) ticket = __hip_atomic_fetch_add(&counters[it.long_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != it.num_items - 1) return;
+    if (ticket != it.num_items - 1) continue;
     // lanes 0..7 own tile row `r`; lane group g = lane/8 walks items g, g+8, ...; fixed order
     const int r = lane & 7, g = lane >> 3;
     A sum = 0;
@@ -418,6 +462,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *_
     const uint32_t row = it.row_begin * 8u + (uint32_t)r;
     if (g == 0 && row < num_rows) y[row] = sum;
     if (lane == 0) __hip_atomic_store(&counters[it.long_idx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -605,8 +650,11 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
         }
         const uint32_t n_items = (uint32_t)A->spmv_num_chunks;
         char *mem = (char *)A->spmv_chunks;
-        auto kern = A->spmv_full_tiles * 4 >= A->block_num ? spmv_sweep_kernel<T, true> : spmv_sweep_kernel<T, false>;
-        hipLaunchKernelGGL(kern, dim3((n_items + 3) / 4), dim3(kThreads), 0, st, (const SweepItem *)(mem + 64), n_items,
+        const bool nt = getenv("BMSP_SPMV_NT") != nullptr;
+        const char *pers = getenv("BMSP_SPMV_PERSIST");
+        auto kern = A->spmv_full_tiles * 4 >= A->block_num ? spmv_sweep_kernel<T, true, false> : (nt ? spmv_sweep_kernel<T, false, true> : (pers ? spmv_sweep_kernel<T, false, false, true> : spmv_sweep_kernel<T, false, false>));
+        const uint32_t grid = pers ? std::min<uint32_t>((n_items + 3) / 4, (uint32_t)atoi(pers)) : (n_items + 3) / 4;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, st, (const SweepItem *)(mem + 64), n_items,
                            A->keys, A->bmps, A->offsets, (const T *)A->values, (const T *)v, (Ac *)u,
                            (Ac *)(mem + A->spmv_plan_off_carry), (uint32_t *)(mem + A->spmv_plan_off_cnt), (uint32_t)A->num_rows,
                            (uint32_t)A->num_cols, (uint32_t)((size_t)A->values_extent() * sizeof(T)));

@@ -226,10 +226,55 @@ def test_spmv_half_and_double(bmsp, dtype, case):
     want = S @ x.astype(np.float64)
     mag = abs(S) @ np.abs(x.astype(np.float64))
     tol = 1e-5 if dtype == 1 else 1e-13  # fp32 accumulation of exact fp16 products / fp64
-    for variant in (0, 1):
+    for variant in (0, 1, 3):
         y = bmsp.DeviceArray(n, bmsp.OUT_DTYPE[dtype])
         bmsp.check(bmsp.lib().bmsp_spmv(A.h, bmsp.DeviceArray.from_host(x).ptr, y.ptr, variant, None))
         assert np.all(np.abs(y.to_host().astype(np.float64) - want) <= tol * mag + 1e-30)
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("case", ["banded_ragged", "partial_nibbles", "empty_rows_wide", "long_row", "fem"])
+def test_spmv_rowgroup_kernel(bmsp, dtype, case):
+    """variant 3 (16 lanes per block-row, 16-byte value loads; the default for matrices with dense tiles): ragged last block row
+    AND column (num_cols % 4 != 0: the 16-byte x load must not be used across the end of x), partly filled nibbles at every
+    alignment (fp16 values start at odd halves), empty block-rows (written as 0 over a NaN-poisoned y), a block-row longer than
+    one trip; against scipy float64 on the rounded inputs; two sweeps bit-identical (register sums, no atomics)."""
+    import scipy.sparse as sp
+    from pybmsp import gen
+    if case == "banded_ragged":
+        nr = nc = 1003
+        _, _, r, c, v = gen.banded(1003, 21)
+    elif case == "partial_nibbles":
+        nr, nc = 777, 1234
+        _, _, r, c, v = gen.random_coo(nr, nc, 120000, seed=11)  # ~12 values per tile, every nibble pattern
+    elif case == "empty_rows_wide":
+        nr, nc = 4001, 515
+        _, _, r, c, v = gen.random_coo(nr, nc, 60000, seed=12)
+        keep = (r // 8) % 3 != 1  # every third block-row empty
+        r, c, v = r[keep], c[keep], v[keep]
+    elif case == "long_row":
+        nr, nc = 40, 30011
+        _, _, r, c, v = gen.random_coo(nr, nc, 400000, seed=13)
+    else:
+        nr, _, r, c, v = gen.fem_like(12, "27pt", window=8)
+        nc = nr
+    np_in = bmsp.NP_DTYPE[dtype]
+    vq = np.asarray(v, np.float64).astype(np_in)
+    A = bmsp.BmSpMatrix.from_coo(nr, nc, r, c, v, dtype=dtype)
+    x = gen.spmv_x(nc, "cusp").astype(np_in)
+    S = sp.coo_matrix((vq.astype(np.float64), (r, c)), shape=(nr, nc)).tocsr()
+    want = S @ x.astype(np.float64)
+    mag = abs(S) @ np.abs(x.astype(np.float64))
+    tol = {0: 1e-5, 1: 1e-5, 2: 1e-13}[dtype]
+    dx = bmsp.DeviceArray.from_host(x)
+    got = []
+    for rep in range(2):
+        y = bmsp.DeviceArray(nr, bmsp.OUT_DTYPE[dtype])
+        assert bmsp.lib().bmsp_memset(y.ptr, 0xFF, nr * y.dtype.itemsize) == 0
+        bmsp.check(bmsp.lib().bmsp_spmv(A.h, dx.ptr, y.ptr, 3, None))
+        got.append(y.to_host())
+        assert np.all(np.abs(got[-1].astype(np.float64) - want) <= tol * mag + 1e-30)
+    np.testing.assert_array_equal(got[0].view(np.uint8), got[1].view(np.uint8))
 
 
 def test_spmv_bench_size_properties(bmsp):
