@@ -396,58 +396,55 @@ def scalar_products(np, A):
 
 
 def bench_spmv_sharded(B, np, torch, dist, rank, world, A, x, y_whole):
-    """SURVEY 8(e), SpMV row: ONE matrix cut into nnz-balanced block-row panels, x replicated, y slices all-gathered (strong
-    scaling; the headline `value` above is the weak-scaling replica rate)."""
-    from pybmsp import shard
-    bounds = shard.spmv_row_bounds(A, world)
-    view = A.row_panel(int(bounds[rank]), int(bounds[rank + 1]))  # built once: keeps its sweep plan across products
-    full, st = shard.spmv_sharded(A, x, rank, world, dist, torch, bounds, view)  # warm-up, and the check below
-    ref = torch.empty_like(full)
-    B.check(B.lib().bmsp_memcpy_d2d(ref.data_ptr(), y_whole.ptr, full.numel() * full.element_size()))
-    same = bool(torch.equal(full, ref))
+    """SURVEY 8(e), SpMV row: ONE matrix cut into nnz-balanced block-row panels, x replicated, y slices exchanged in place over RCCL
+    through the C ABI (bmsp_spmv_sharded); strong scaling; the headline `value` above is the weak-scaling replica rate."""
+    comm = B.Comm.from_torch(dist, torch)
+    y, sh = B.spmv_sharded(comm, A, x)  # warm-up (builds the panel view and its plan), and the check below
+    same = bool(np.array_equal(y.to_host(), y_whole.to_host()))
     reps = 20
-    torch.cuda.synchronize(); dist.barrier()
+    B.synchronize(); dist.barrier()
     t0 = time.perf_counter()
-    gather_ms = 0.0
+    ex_us = 0.0
     for _ in range(reps):
-        full, st = shard.spmv_sharded(A, x, rank, world, dist, torch, bounds, view)
-        gather_ms += st["gather_ms"]
-    torch.cuda.synchronize(); dist.barrier()
+        y, sh = B.spmv_sharded(comm, A, x, y)
+        ex_us += sh["exchange_us"]
+    B.synchronize(); dist.barrier()
     ms = (time.perf_counter() - t0) * 1e3 / reps
-    return {"workload": "one matrix, row panels balanced by nnz, y all-gathered", "scaling": "strong", "n_gpus": world,
-            "ms_per_product": round(ms, 4), "allgather_ms": round(gather_ms / reps, 4), "allgather_bytes": st["gather_bytes"],
+    comm.free()
+    return {"workload": "one matrix, row panels balanced by nnz, y slices broadcast in place (bmsp_spmv_sharded, RCCL)", "scaling": "strong", "n_gpus": world,
+            "ms_per_product": round(ms, 4), "exchange_ms": round(ex_us / reps * 1e-3, 4), "exchange_bytes": sh["exchange_bytes"],
             "matches_single_gpu_sweep": same}
 
 
 def bench_spgemm_sharded(B, gen, np, torch, dist, rank, world):
-    """configs[4]: row-panel-sharded SpGEMM on R-MAT scale 22 with an allgatherv of the C panels over RCCL; fixed total work ->
-    strong scaling.  Edge factor 1 (+ identity): 2.3 G candidate block pairs, 0.69 G surviving tasks, 0.48 G C blocks -- the largest
-    scale-22 instance whose single panel (N = 1) stays inside the 32-bit candidate range, so that N = 1, 2, 4, 8 run the same product
-    (edge factor 2 has 7.9 G candidates)."""
-    from pybmsp import shard
+    """configs[4]: row-panel-sharded SpGEMM on R-MAT scale 22 with the allgatherv of the C panels over RCCL (bmsp_spgemm_sharded: panels
+    broadcast straight into their final slices); fixed total work -> strong scaling.  Edge factor 1 (+ identity): 2.3 G candidate block
+    pairs, 0.69 G surviving tasks, 0.48 G C blocks -- the largest scale-22 instance whose single panel (N = 1) stays inside the 32-bit
+    candidate range, so that N = 1, 2, 4, 8 run the same product (edge factor 2 has 7.9 G candidates)."""
     scale = int(os.environ.get("BMSP_SHARD_SCALE", "22"))
     ef = float(os.environ.get("BMSP_SHARD_EF", "1"))
     n, _, r, c, v = gen.rmat(scale, ef)
-    A = B.BmSpMatrix.from_coo(n, n, r, c, v, dtype=B.F16)
-    Bt = B.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=B.F16)
+    A = B.BmSpMatrix.from_coo(n, n, r, c, v, dtype=B.F16).prepare(2)
+    Bt = B.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=B.F16).prepare(2)
+    comm = B.Comm.from_torch(dist, torch)
     best = None
     for it in range(3):
         B.synchronize(); dist.barrier()
         t0 = time.perf_counter()
-        Cm, stats = shard.spgemm_sharded(A, Bt, rank, world, dist, torch, tc_version=4)
+        Cm, st, sh = B.spgemm_sharded(comm, A, Bt, tc_version=4)
         B.synchronize(); dist.barrier()
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt, stats["panel"]["t_us"][0] * 1e-6], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, st["t_us"][0] * 1e-6], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if it and (best is None or float(t[0].item()) < best[0]):
-            best = (float(t[0].item()), stats, Cm.info(), float(t[1].item()))
+            best = (float(t[0].item()), sh, Cm.info(), float(t[1].item()))
         del Cm
+    comm.free()
     P = scalar_products(np, A) if rank == 0 else 0
     return {"workload": "row-panel-sharded SpGEMM fp16 MFMA, rmat(scale=%d, ef=%g)+I" % (scale, ef), "scaling": "strong", "n_gpus": world,
             "total_ms": round(best[0] * 1e3, 3), "slowest_panel_product_ms": round(best[3] * 1e3, 3), "gflops": round(2.0 * P / best[0] / 1e9, 2),
-            "c_blocks": best[2]["block_num"],
-            "c_nnz": best[2]["nnz"], "allgatherv_bytes": best[1]["gather_bytes"], "allgatherv_ms": round(best[1]["gather_ms"], 3),
-            "panel_tasks": best[1]["tasks"]}
+            "c_blocks": best[2]["block_num"], "c_nnz": best[2]["nnz"], "allgatherv_bytes": best[1]["exchange_bytes"],
+            "allgatherv_ms": round(best[1]["exchange_us"] * 1e-3, 3), "panel_tasks": best[1]["panel_tasks"]}
 
 
 def host_threads(O):

@@ -461,6 +461,63 @@ int bmsp_spmv(bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *st
     BMSP_API_END
 }
 
+int bmsp_comm_unique_id(void *id_bytes)
+{
+    BMSP_API_BEGIN
+    need(id_bytes, "id_bytes");
+    comm_unique_id(id_bytes);
+    BMSP_API_END
+}
+
+int bmsp_comm_init(const void *id_bytes, int world, int rank, bmsp_comm_t *out)
+{
+    BMSP_API_BEGIN
+    need(id_bytes, "id_bytes"); need(out, "out");
+    *out = comm_init(id_bytes, world, rank);
+    BMSP_API_END
+}
+
+int bmsp_comm_init_from_env(bmsp_comm_t *out)
+{
+    BMSP_API_BEGIN
+    need(out, "out");
+    *out = comm_init_from_env();
+    BMSP_API_END
+}
+
+int bmsp_comm_info(bmsp_comm_t c, int *rank, int *world)
+{
+    BMSP_API_BEGIN
+    need(c, "comm");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    BMSP_API_END
+}
+
+int bmsp_comm_free(bmsp_comm_t c)
+{
+    BMSP_API_BEGIN
+    comm_free(c);
+    BMSP_API_END
+}
+
+int bmsp_spgemm_sharded(bmsp_comm_t c, bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, int verbose, void *stream,
+                        bmsp_spgemm_stats *stats, bmsp_shard_stats *shard)
+{
+    BMSP_API_BEGIN
+    need(c, "comm"); need(A, "A"); need(B, "B"); need(C, "C");
+    spgemm_sharded(c, A, B, C, mode, tc_version, verbose, as_stream(stream), stats, shard);
+    BMSP_API_END
+}
+
+int bmsp_spmv_sharded(bmsp_comm_t c, bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *stream, bmsp_shard_stats *shard)
+{
+    BMSP_API_BEGIN
+    need(c, "comm"); need(A, "A");
+    spmv_sharded(c, A, d_v, d_u, variant, as_stream(stream), shard);
+    BMSP_API_END
+}
+
 int bmsp_selftest_mfma_layout(int *mismatches)
 {
     BMSP_API_BEGIN

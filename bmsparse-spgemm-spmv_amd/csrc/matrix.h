@@ -32,12 +32,22 @@ struct bmsp_matrix_s {
     void *dense_tiles = nullptr;
     // a row-panel view points into its parent
     int64_t view_block_begin = 0;
+    // sharded SpMV (comm.hip): this rank's panel view, kept for its cached sweep plan
+    bmsp_matrix_s *shard_view = nullptr;
+    int shard_world = 0, shard_rank = 0;
+    std::vector<int64_t> shard_bounds;
 
     int64_t view_values_end = 0;  // row-panel views: end (in elements) of the panel's values inside the parent's array
     // elements addressable from `values`: offsets of a view stay absolute into the parent's value array
     int64_t values_extent() const { return view_values_end ? view_values_end : nnz; }
     int64_t num_block_rows() const { return ((int64_t)num_rows + 7) / 8; }
     int64_t num_block_cols() const { return ((int64_t)num_cols + 7) / 8; }
+};
+
+// one RCCL communicator (bmsp_comm_t); `comm` is an ncclComm_t
+struct bmsp_comm_s {
+    void *comm = nullptr;
+    int rank = 0, world = 1, device = 0;
 };
 
 namespace bmsp {
@@ -90,6 +100,15 @@ struct PingPong;
 bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st);
 void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const int *d_segs, int64_t num_segs,
                  hipStream_t st);
+
+// multi-GPU (comm.hip)
+void comm_unique_id(void *id128);
+bmsp_comm_s *comm_init(const void *id128, int world, int rank);
+bmsp_comm_s *comm_init_from_env();
+void comm_free(bmsp_comm_s *c);
+void spgemm_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int tc_version, int verbose, hipStream_t st,
+                    bmsp_spgemm_stats *stats, bmsp_shard_stats *sh);
+void spmv_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, const void *x, void *y, int variant, hipStream_t st, bmsp_shard_stats *sh);
 
 }  // namespace bmsp
 #endif

@@ -27,7 +27,15 @@ int main(int argc, char **argv)
     std::cout << "A matrix: " << A_path << std::endl;
     std::cout << "B matrix: " << B_path << std::endl;
     try {
-        bmsp::check(bmsp_set_device(0));
+        // BMSP_WORLD / BMSP_RANK (+ BMSP_COMM_FILE): one process per GPU, the product is sharded by block-row panels of A and every
+        // rank ends with the whole C (bmsp_spgemm_sharded); unset = the reference's single-GPU run
+        const char *world_env = getenv("BMSP_WORLD");
+        const int world = world_env ? atoi(world_env) : 1, rank = getenv("BMSP_RANK") ? atoi(getenv("BMSP_RANK")) : 0;
+        int ndev = 1;
+        bmsp::check(bmsp_device_count(&ndev));
+        bmsp::check(bmsp_set_device(getenv("BMSP_DEVICE") ? atoi(getenv("BMSP_DEVICE")) : (world_env ? rank % ndev : 0)));
+        bmsp_comm_t comm = nullptr;
+        if (world_env) bmsp::check(bmsp_comm_init_from_env(&comm));
         auto t0 = std::chrono::steady_clock::now();
         bmSpMatrix<half> A_bmSp(A_path + ".mtx", false);
         bmSpMatrix<half> B_bmSp(B_path + ".mtx", true);
@@ -37,11 +45,18 @@ int main(int argc, char **argv)
 
         bmSpMatrix<OUTPUT_TYPE> C;
         t0 = std::chrono::steady_clock::now();
-        bmSparse_mult(A_bmSp, B_bmSp, C, segmented != 0, VERBOSE, tc_version);
+        bmsp_shard_stats sh{};
+        if (comm) bmSparse_mult_sharded(comm, A_bmSp, B_bmSp, C, segmented != 0, VERBOSE, tc_version, nullptr, &sh);
+        else bmSparse_mult(A_bmSp, B_bmSp, C, segmented != 0, VERBOSE, tc_version);
         us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
         std::cout << "bmSparse execution: " << us << " \xce\xbcs" << std::endl;
         std::cout << "C blocks: " << C.keys.size() << std::endl;
         std::cout << "C nnz: " << C.nnz << std::endl;
+        if (comm) {
+            std::cout << "rank " << sh.rank << " of " << sh.world << ": block-rows [" << sh.panel_block_row_begin << ", " << sh.panel_block_row_end << "), "
+                      << sh.panel_tasks << " tasks, exchange " << sh.exchange_bytes << " bytes in " << (long long)(sh.exchange_us + 0.5) << " \xce\xbcs" << std::endl;
+            bmsp_comm_free(comm);
+        }
         if (getenv("BMSP_PRINT_CHECKSUM")) {
             double s = 0;
             for (float x : C.values.to_host()) s += x;

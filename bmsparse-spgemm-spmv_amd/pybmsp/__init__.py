@@ -29,6 +29,7 @@ SYMBOLS = [
     "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_prepare", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
     "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmm", "bmsp_spgemm", "bmsp_selftest_mfma_layout", "bmsp_segsort_u64",
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
+    "bmsp_comm_unique_id", "bmsp_comm_init", "bmsp_comm_init_from_env", "bmsp_comm_info", "bmsp_comm_free", "bmsp_spgemm_sharded", "bmsp_spmv_sharded",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
     "bmsp_csr_spmv", "bmsp_csr_free",
 ]
@@ -50,6 +51,14 @@ class SpgemmStats(C.Structure):
                                            "sort_path", "mac_kernel")}
         d["t_us"] = list(self.t_us)
         return d
+
+
+class ShardStats(C.Structure):
+    _fields_ = [("world", C.c_int), ("rank", C.c_int), ("panel_block_row_begin", C.c_int64), ("panel_block_row_end", C.c_int64),
+                ("panel_tasks", C.c_int64), ("exchange_bytes", C.c_int64), ("exchange_us", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 _lib = None
@@ -105,6 +114,13 @@ def lib():
         L.bmsp_partition_rows.argtypes = [vp, vp, i, vp]
         L.bmsp_matrix_row_panel.argtypes = [vp, i64, i64, p(vp)]
         L.bmsp_matrix_concat_panels.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, i, p(vp)]
+        L.bmsp_comm_unique_id.argtypes = [vp]
+        L.bmsp_comm_init.argtypes = [vp, i, i, p(vp)]
+        L.bmsp_comm_init_from_env.argtypes = [p(vp)]
+        L.bmsp_comm_info.argtypes = [vp, p(i), p(i)]
+        L.bmsp_comm_free.argtypes = [vp]
+        L.bmsp_spgemm_sharded.argtypes = [vp, vp, vp, p(vp), i, i, i, vp, p(SpgemmStats), p(ShardStats)]
+        L.bmsp_spmv_sharded.argtypes = [vp, vp, vp, vp, i, vp, p(ShardStats)]
         L.bmsp_csr_from_mtx.argtypes = [C.c_char_p, p(vp)]
         L.bmsp_csr_from_arrays.argtypes = [i, i, i64, vp, vp, vp, p(vp)]
         L.bmsp_csr_info.argtypes = [vp, p(i), p(i), p(i64)]
@@ -421,6 +437,57 @@ def concat_panels(num_rows, num_cols, panels, dtype=F32):
     check(lib().bmsp_matrix_concat_panels(int(num_rows), int(num_cols), P, bn.ctypes.data, nz.ctypes.data, k, b, o, v, dtype,
                                           C.byref(h)))
     return BmSpMatrix(h.value)
+
+
+class Comm:
+    """one RCCL communicator behind the C ABI (bmsp_comm_t): rank 0 makes the id, every rank calls Comm(id, world, rank)."""
+
+    def __init__(self, id_bytes, world, rank):
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        check(lib().bmsp_comm_init(buf, int(world), int(rank), C.byref(h)))
+        self.h, self.world, self.rank = h.value, int(world), int(rank)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().bmsp_comm_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def from_torch(dist, torch):
+        """rendezvous over an existing torch.distributed group (the id travels as 128 bytes in a broadcast)."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return Comm(box[0], world, rank)
+
+    def free(self):
+        if self.h:
+            lib().bmsp_comm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def spgemm_sharded(comm, A, B, mode=SORT_AUTO, tc_version=5, verbose=False, stream=None):
+    h = C.c_void_p()
+    st, sh = SpgemmStats(), ShardStats()
+    check(lib().bmsp_spgemm_sharded(comm.h, A.h, B.h, C.byref(h), int(mode), int(tc_version), int(bool(verbose)), stream, C.byref(st), C.byref(sh)))
+    return BmSpMatrix(h.value), st.as_dict(), sh.as_dict()
+
+
+def spmv_sharded(comm, A, v, u=None, variant=0, stream=None):
+    i = A.info()
+    if u is None:
+        u = DeviceArray(i["num_rows"], OUT_DTYPE[i["dtype"]])
+    sh = ShardStats()
+    check(lib().bmsp_spmv_sharded(comm.h, A.h, v.ptr, u.ptr, int(variant), stream, C.byref(sh)))
+    return u, sh.as_dict()
 
 
 class CSRMatrix:

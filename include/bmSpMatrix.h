@@ -249,4 +249,19 @@ inline void bmSparse_mult(bmSpMatrix<valueIn> &A, bmSpMatrix<valueIn> &B, bmSpMa
     std::printf("Toda F: %lld \xce\xbcs \n", (long long)(st.t_us[0] + 0.5)); /* :1220 */
 }
 
+/* The same product sharded over one process per GPU (bmsp_spgemm_sharded): every rank passes the same A and B, multiplies
+ * its block-row panel of A and returns the whole C. */
+template <class valueIn, class valueOut>
+inline void bmSparse_mult_sharded(bmsp_comm_t comm, bmSpMatrix<valueIn> &A, bmSpMatrix<valueIn> &B, bmSpMatrix<valueOut> &C, bool mode, bool VERBOSE,
+                                  long tc_version, bmsp_spgemm_stats *stats = nullptr, bmsp_shard_stats *shard = nullptr)
+{
+    bmsp_matrix_t c = nullptr;
+    bmsp_spgemm_stats st;
+    bmsp::check(bmsp_spgemm_sharded(comm, A.handle(), B.handle(), &c, mode ? BMSP_SORT_SEGMENTED : BMSP_SORT_AUTO, (int)tc_version, VERBOSE ? 1 : 0,
+                                    nullptr, &st, shard));
+    C.reset(c);
+    if (stats) *stats = st;
+    std::printf("Toda F: %lld \xce\xbcs \n", (long long)(st.t_us[0] + 0.5));
+}
+
 #endif /* BMSPMATRIX_H_ */

@@ -209,7 +209,7 @@ int bmsp_segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, c
                      int64_t num_segs, void *stream);
 
 /* ---- row-panel sharding (new; the reference is single-GPU).  One process per GPU: each rank calls these
- *      with its own rank id; the exchange of panels is done by the host side over RCCL. ---------------- */
+ *      with its own rank id.  These three are the building blocks; bmsp_spgemm_sharded below runs the whole thing. ---- */
 
 /* Splits A's block-rows into `parts` contiguous panels balanced by candidate-task count
  * (sum over the panel's A blocks of B's blocks in the matching block-row).  bounds receives parts+1
@@ -224,6 +224,38 @@ int bmsp_matrix_concat_panels(int num_rows, int num_cols, int parts, const int64
                               const int64_t *nnzs, uint64_t *const *d_keys, uint64_t *const *d_bmps,
                               uint64_t *const *d_offsets, void *const *d_values, bmsp_dtype dtype,
                               bmsp_matrix_t *out);
+
+/* ---- the sharded operators themselves: one process per GPU, RCCL over xGMI (nothing in the reference to
+ *      replace -- it is single-GPU: src/bmSparse_SPGEMM.cu:1226-1288 runs one product on device 0).  librccl is opened on the first
+ *      bmsp_comm_* call, not at load time. -------------------------------------------------------------------------------- */
+typedef struct bmsp_comm_s *bmsp_comm_t;
+#define BMSP_COMM_ID_BYTES 128
+/* rank 0 creates the 128-byte rendezvous id (ncclUniqueId) and hands it to the other ranks by any means (file, MPI, torch.distributed) */
+int bmsp_comm_unique_id(void *id_bytes);
+/* collective: every rank calls it with the same id, after bmsp_set_device(its GPU) */
+int bmsp_comm_init(const void *id_bytes, int world, int rank, bmsp_comm_t *out);
+/* the same from the environment, for the drop-in executables: BMSP_WORLD, BMSP_RANK and, when BMSP_WORLD > 1, BMSP_COMM_FILE (a path
+ * every rank can reach: rank 0 writes the id there, the others wait for it) */
+int bmsp_comm_init_from_env(bmsp_comm_t *out);
+int bmsp_comm_info(bmsp_comm_t c, int *rank, int *world);
+int bmsp_comm_free(bmsp_comm_t c);
+
+typedef struct {
+    int world, rank;
+    int64_t panel_block_row_begin, panel_block_row_end; /* this rank's block-rows of A */
+    int64_t panel_tasks;                                /* surviving tasks of this rank's panel (SpGEMM) */
+    int64_t exchange_bytes;                             /* bytes every rank holds after the exchange (whole C / whole y) */
+    double exchange_us;                                 /* device time of the exchange on this rank */
+} bmsp_shard_stats;
+
+/* C = A * B with A cut into `world` block-row panels balanced by candidate-task count, B replicated (every rank passes the same A
+ * and B), every rank multiplies its panel and ALL ranks return the whole C: the panels are broadcast straight into their final
+ * slices (an allgatherv without padding or staging copies), offsets re-based in place.  stats = this rank's panel product. */
+int bmsp_spgemm_sharded(bmsp_comm_t c, bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, int verbose,
+                        void *stream, bmsp_spgemm_stats *stats, bmsp_shard_stats *shard);
+/* u = A * v with A cut into block-row panels balanced by stored values, v replicated; every rank sweeps its panel and all ranks
+ * return the whole u (num_rows entries).  The panel view and its sweep plan are cached on A across calls. */
+int bmsp_spmv_sharded(bmsp_comm_t c, bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *stream, bmsp_shard_stats *shard);
 
 /* ---- host CSR (class CSRMatrix, include/CSRMatrix.h:13-21; declared only in the reference; backed by
  *      cusp::csr_matrix<int,float,host_memory> and cusp::multiply) ---------------------------------- */

@@ -792,6 +792,32 @@ def test_row_panel_views_fp16_mfma_and_spmv(oracle, bmsp):
     assert not yp[: lo * 8].any() and not yp[hi * 8:].any()
 
 
+def test_sharded_operators_through_c_abi_one_rank(oracle, bmsp):
+    """bmsp_comm_init / bmsp_spgemm_sharded / bmsp_spmv_sharded over a real RCCL communicator of one rank (all a one-GPU box
+    allows: RCCL refuses two ranks on one device): the unique-id rendezvous, the size all-gather, the broadcast of the panel into
+    its final slice, offset re-basing and the in-place y exchange all run; results equal the unsharded operators bit for bit."""
+    from pybmsp import gen
+    comm = bmsp.Comm(bmsp.Comm.unique_id(), 1, 0)
+    n, _, r, c, v = gen.rmat(12, 6)
+    for dtype, tc in ((0, 5), (1, 4)):
+        A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=dtype)
+        Bt = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=dtype)
+        whole, st0 = bmsp.spgemm(A, Bt, tc_version=tc)
+        Cs, st, sh = bmsp.spgemm_sharded(comm, A, Bt, tc_version=tc)
+        assert (sh["world"], sh["rank"], sh["panel_block_row_begin"], sh["panel_block_row_end"]) == (1, 0, 0, (n + 7) // 8)
+        assert sh["panel_tasks"] == st0["surviving_tasks"] and sh["exchange_bytes"] == 24 * whole.block_num + 4 * whole.nnz
+        for x, y in zip(Cs.host_arrays(), whole.host_arrays()):
+            np.testing.assert_array_equal(x, y)
+    Af = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    x = bmsp.DeviceArray.from_host(gen.spmv_x(n, "cusp"))
+    y0 = bmsp.spmv(Af, x).to_host()
+    for _ in range(2):  # second call reuses the cached panel view
+        y1, sh = bmsp.spmv_sharded(comm, Af, x)
+        np.testing.assert_array_equal(y1.to_host(), y0)
+    assert sh["exchange_bytes"] == 4 * n
+    comm.free()
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_row_panel_views_expand_and_compare(bmsp, dtype):
     """a NON-first panel view (offsets absolute into the parent's values, outputs sized by the view's own nnz) through every
@@ -1016,6 +1042,11 @@ def test_cli_executables_and_batch_scripts(tmp_path):
             pos = nxt
         if seg == "1":
             assert "Segmented sort: " in text
+    # the sharded form of the same executable (one rank: BMSP_WORLD=1 needs no rendezvous file): same answer through RCCL
+    out = subprocess.run([os.path.join(REPO, "bmsparse_spgemm_float"), folder, "A_matrix", "B_matrix", "0", "4", "0"], capture_output=True, text=True,
+                         env=dict(env, BMSP_WORLD="1", BMSP_RANK="0"))
+    assert out.returncode == 0, out.stderr
+    assert "C blocks: 9" in out.stdout and "C nnz: 255" in out.stdout and "C checksum: 1070" in out.stdout and "rank 0 of 1: block-rows [0, 3), 27 tasks" in out.stdout
     # usage errors: exit code 1 and the reference's usage line
     out = subprocess.run([os.path.join(REPO, "bmsparse_spgemm_float"), folder], capture_output=True, text=True)
     assert out.returncode == 1 and "./main MatrixFolder A_Matrix B_Matrix" in out.stdout
