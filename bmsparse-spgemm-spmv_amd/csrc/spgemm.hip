@@ -142,6 +142,123 @@ __global__ __launch_bounds__(kThreads) void expand_filter_kernel(ExpandArgs g, u
     }
 }
 
+// ---- T_3 + T_4 in ONE pass: decoupled look-back over the tiles -------------------------------------------------------------
+// The count + write pair above evaluates every candidate twice.  Here a workgroup evaluates its tile once (the surviving pairs stay
+// in registers), publishes the tile's survivor count in a status word {flag, count}, takes the sum of all earlier tiles by looking
+// back over their status words (aggregate / inclusive-prefix protocol), and writes its survivors at that position.  Tile ids are
+// handed out by an atomic counter, so a workgroup only ever waits for tiles that have already started.  Each status word is ONE
+// 8-byte agent-scope atomic store / load ({flag, value} in a single granule: nothing else has to be ordered around it).  The
+// output is allocated for the candidate count (the upper bound) instead of the survivor count.
+constexpr uint64_t kTileAgg = 1ull << 62, kTilePrefix = 2ull << 62;
+
+template <int ITEMS>
+__global__ __launch_bounds__(kThreads) void expand_filter_lookback_kernel(ExpandArgs g, unsigned long long *__restrict__ tile_state, uint32_t *__restrict__ tile_counter,
+                                                                          uint32_t num_tiles, uint64_t *__restrict__ out_keys, uint64_t *__restrict__ out_tasks,
+                                                                          uint32_t *__restrict__ n_tasks_host)
+{
+    __shared__ uint32_t rel[kSpanMax + 1];
+    __shared__ uint32_t range[2];
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t s_tile, s_prefix;
+    constexpr uint32_t kTileE = (uint32_t)ITEMS * kThreads;
+    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint64_t t0 = (uint64_t)tile * kTileE;
+    const uint64_t t1 = (t0 + (uint64_t)kTileE < g.total) ? t0 + (uint64_t)kTileE : g.total;
+    if (threadIdx.x == 0) range[0] = upper_bound_u64(g.first_pos, 0, (uint32_t)g.n_a + 1, t0) - 1;
+    if (threadIdx.x == 64) range[1] = upper_bound_u64(g.first_pos, 0, (uint32_t)g.n_a + 1, t1 - 1) - 1;
+    __syncthreads();
+    const uint32_t a_lo = range[0], a_hi = range[1];
+    const uint32_t span = a_hi - a_lo + 1;
+    const bool staged = span <= (uint32_t)kSpanMax;
+    if (staged) {
+        for (uint32_t k = threadIdx.x; k <= span; k += kThreads) {
+            uint64_t fp = g.first_pos[a_lo + k];
+            rel[k] = fp <= t0 ? 0u : (fp - t0 < (uint64_t)kTileE ? (uint32_t)(fp - t0) : kTileE);
+        }
+    }
+    __syncthreads();
+    // evaluate the tile once: surviving pairs stay in registers (~0 = dropped)
+    uint64_t pair[ITEMS];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint64_t t = t0 + (uint64_t)k * kThreads + threadIdx.x;
+        pair[k] = ~0ull;
+        if (t < t1) {
+            const uint32_t lt = (uint32_t)(t - t0);
+            uint32_t a;
+            if (staged) {
+                uint32_t lo = 0, hi = span;
+                while (lo < hi) {
+                    uint32_t mid = lo + ((hi - lo + 1) >> 1);
+                    if (rel[mid] <= lt) lo = mid;
+                    else hi = mid - 1;
+                }
+                a = a_lo + lo;
+            } else {
+                a = upper_bound_u64(g.first_pos, a_lo, a_hi + 1, t) - 1;
+            }
+            const uint32_t b = g.b_rowptr[key_col(g.a_keys[a])] + (uint32_t)(t - g.first_pos[a]);
+            if (!tile_product_empty(g.a_bmps[a], g.b_bmps[b])) {  // multiplication_checker (:742-757)
+                pair[k] = ((uint64_t)a << 32) | (uint64_t)b;
+                mine++;
+            }
+        }
+    }
+    // tile total -> status word -> look back
+    const uint32_t wsum = wave_sum(mine);
+    if (lane_id() == 0) lds4[wave_id()] = wsum;
+    __syncthreads();
+    const uint32_t tile_total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    if (wave_id() == 0) {
+        const int lane = lane_id();
+        if (lane == 0)
+            __hip_atomic_store(&tile_state[tile], (tile == 0 ? kTilePrefix : kTileAgg) | (uint64_t)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t prefix = 0;
+        int64_t look = (int64_t)tile - 1;  // newest tile not yet accounted for
+        while (look >= 0) {
+            const int64_t idx = look - lane;
+            unsigned long long w = kTilePrefix;  // lanes before tile 0 read as "prefix 0"
+            if (idx >= 0) {
+                do {
+                    w = __hip_atomic_load(&tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(w >> 62)) __builtin_amdgcn_s_sleep(1);
+                } while (!(w >> 62));
+            }
+            const uint64_t is_prefix = __ballot((w >> 62) == 2ull);
+            // lanes up to and including the first inclusive prefix count
+            const int stop = is_prefix ? __builtin_ctzll(is_prefix) : 63;
+            uint32_t v = lane <= stop ? (uint32_t)w : 0u;
+            prefix += wave_sum(v);
+            if (is_prefix) break;
+            look -= 64;
+        }
+        if (lane == 0) {
+            s_prefix = prefix;
+            if (tile != 0)
+                __hip_atomic_store(&tile_state[tile], kTilePrefix | (uint64_t)(prefix + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tile == num_tiles - 1) *n_tasks_host = prefix + tile_total;
+        }
+    }
+    __syncthreads();
+    // write the survivors in candidate order
+    uint32_t carry = s_prefix;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const bool keep = pair[k] != ~0ull;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_sum<uint32_t>(keep ? 1u : 0u, lds4, total);
+        if (keep) {
+            const uint32_t a = (uint32_t)(pair[k] >> 32), b = (uint32_t)pair[k];
+            out_keys[carry + ex] = ((uint64_t)key_row(g.a_keys[a]) << g.jbits) | (uint64_t)key_col(g.b_keys[b]);
+            out_tasks[carry + ex] = pair[k];
+        }
+        carry += total;
+    }
+}
+
 struct CountIn {
     const uint32_t *p;
     uint64_t n;
@@ -786,7 +903,26 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     DevBuf<uint32_t> tile_counts((size_t)tiles + 1);
     uint64_t n_tasks = 0;
     DevBuf<uint64_t> k0, k1, v0, v1;
-    if (total) {
+    // The single-pass form (decoupled look-back, candidate-sized output) is kept as an option: measured on MI355X it costs what the
+    // count + write pair costs (cage-like 224 vs 106 + 128 us, FEM-like 358 vs 147 + 210 us) and loses on small products (full-tile
+    // banded 69 vs 49 us): a workgroup holds its slot through the look-back and the sixteen ordered block scans of the write.
+    const bool lookback = total && total <= (512ull << 20) && getenv("BMSP_EXPAND_LOOKBACK") != nullptr;
+    if (lookback) {
+        tm.mark(3);
+        k0.alloc(total); v0.alloc(total);
+        DevBuf<unsigned long long> state((size_t)tiles + 1);
+        BMSP_HIP(hipMemsetAsync(state.p, 0, 8 * ((size_t)tiles + 1), st));
+        uint32_t *counter = (uint32_t *)(state.p + tiles);
+        HostScalar<uint32_t> n_tasks_h;
+        if (small_product)
+            hipLaunchKernelGGL((expand_filter_lookback_kernel<2>), dim3(tiles), dim3(kThreads), 0, st, ea, state.p, counter, tiles, k0.p, v0.p, n_tasks_h.dev());
+        else
+            hipLaunchKernelGGL((expand_filter_lookback_kernel<kItems>), dim3(tiles), dim3(kThreads), 0, st, ea, state.p, counter, tiles, k0.p, v0.p, n_tasks_h.dev());
+        BMSP_CHECK_LAUNCH();
+        n_tasks = n_tasks_h.wait(st);
+        k1.alloc(n_tasks); v1.alloc(n_tasks);
+        tm.mark(4);
+    } else if (total) {
         if (small_product)
             hipLaunchKernelGGL((expand_filter_kernel<false, 2>), dim3(tiles), dim3(kThreads), 0, st, ea, tile_counts.p, (const uint32_t *)nullptr,
                                (uint64_t *)nullptr, (uint64_t *)nullptr);

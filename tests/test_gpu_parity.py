@@ -441,6 +441,32 @@ def test_mfma32_block_mac_paths(oracle, bmsp, monkeypatch, case, b_dense, quota)
         np.testing.assert_allclose(vn, vo, rtol=2e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", ["rmat", "banded", "filtered", "rect"])
+def test_spgemm_single_pass_expansion(oracle, bmsp, monkeypatch, case):
+    """BMSP_EXPAND_LOOKBACK: T_3 + T_4 as one decoupled look-back pass (survivors written at the running prefix of the earlier tiles);
+    same task order, hence the same C bit for bit as the count + write pair."""
+    from pybmsp import gen
+    monkeypatch.setenv("BMSP_EXPAND_LOOKBACK", "1")
+    if case == "rmat":
+        n, _, r, c, v = gen.rmat(12, 8)
+        A = Bc = (n, n, r, c, v)
+    elif case == "banded":
+        n, _, r, c, v = gen.banded(20011, 9)
+        A = Bc = (n, n, r, c, v)
+    elif case == "filtered":
+        # A only touches column 0 of every tile, B only row 7: every candidate pair dies in the bitmap filter
+        n = 2048
+        ra = np.arange(n); ca = (ra // 8) * 8
+        rb = (np.arange(n) // 8) * 8 + 7; cb = np.arange(n)
+        A, Bc = (n, n, ra, ca, np.ones(n)), (n, n, rb, cb, np.ones(n))
+    else:
+        _, _, r1, c1, v1 = gen.random_coo(3001, 517, 40000, seed=21)
+        _, _, r2, c2, v2 = gen.random_coo(517, 2203, 30000, seed=22)
+        A, Bc = (3001, 517, r1, c1, v1), (517, 2203, r2, c2, v2)
+    for dtype, tc in ((0, 5), (1, 4)):
+        check_spgemm(oracle, bmsp, A, Bc, dtype, 0, tc)
+
+
 def _cusp_pairs():
     g = json.load(open(os.path.join(GOLDEN, "cusp_multiply.json")))
     return [(p["left"], p["right"]) for p in g["products"]]
