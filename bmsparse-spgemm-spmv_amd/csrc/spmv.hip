@@ -297,8 +297,8 @@ __device__ __forceinline__ void peel_commit(const Peeled<T, A, N> &q, A *__restr
 
 // FULL: matrices whose plan counted many full tiles (FEM-like) get the variant with the 16-byte-per-lane full-tile pass; the
 // graph-like default keeps the leaner code (the extra pass costs the webbase-like case 7 % even when it never runs)
-template <typename T, bool FULL, bool NT, bool PERSIST = false>
-__global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(const SweepItem *__restrict__ items, uint32_t num_items,
+template <typename T, bool FULL, bool NT, bool PERSIST = false, int OCC = 1>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, 8))) void spmv_sweep_kernel(const SweepItem *__restrict__ items, uint32_t num_items,
                                                               const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bmps,
                                                               const uint64_t *__restrict__ offsets, const T *__restrict__ values,
                                                               const T *__restrict__ x, typename Acc<T>::type *__restrict__ y,
@@ -652,7 +652,10 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
         char *mem = (char *)A->spmv_chunks;
         const bool nt = getenv("BMSP_SPMV_NT") != nullptr;
         const char *pers = getenv("BMSP_SPMV_PERSIST");
+        const char *occ = getenv("BMSP_SPMV_OCC");
         auto kern = A->spmv_full_tiles * 4 >= A->block_num ? spmv_sweep_kernel<T, true, false> : (nt ? spmv_sweep_kernel<T, false, true> : (pers ? spmv_sweep_kernel<T, false, false, true> : spmv_sweep_kernel<T, false, false>));
+        if (occ && atoi(occ) == 6) kern = spmv_sweep_kernel<T, false, false, false, 6>;
+        if (occ && atoi(occ) == 8) kern = spmv_sweep_kernel<T, false, false, false, 8>;
         const uint32_t grid = pers ? std::min<uint32_t>((n_items + 3) / 4, (uint32_t)atoi(pers)) : (n_items + 3) / 4;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, st, (const SweepItem *)(mem + 64), n_items,
                            A->keys, A->bmps, A->offsets, (const T *)A->values, (const T *)v, (Ac *)u,
