@@ -25,8 +25,8 @@ const std::string &last_error() { return g_last_error; }
 namespace {
 struct Pool {
     std::mutex mu;
-    std::map<size_t, std::vector<void *>> free_blocks;  // rounded size -> blocks
-    std::unordered_map<void *, size_t> live;            // every block we ever allocated -> rounded size
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_blocks;  // (device, rounded size) -> blocks
+    std::unordered_map<void *, std::pair<int, size_t>> live;            // every block we ever allocated -> (device, rounded size)
     ~Pool() {}                                          // leave memory to process teardown (runtime may be gone)
 };
 Pool &pool()
@@ -50,10 +50,12 @@ void *pool_alloc(size_t bytes)
     // every block carries kPoolSlack readable bytes past the requested size: kernels that fetch a tile's values with one wide
     // load may touch (and discard) up to 12 bytes beyond the last stored value
     size_t r = round_size(bytes + kPoolSlack);
+    int dev = 0;
+    (void)hipGetDevice(&dev);  // a block is only ever handed out on the device it was allocated on (bmsp_set_device may change it)
     Pool &P = pool();
     {
         std::lock_guard<std::mutex> lk(P.mu);
-        auto it = P.free_blocks.find(r);
+        auto it = P.free_blocks.find(std::make_pair(dev, r));
         if (it != P.free_blocks.end() && !it->second.empty()) {
             void *p = it->second.back();
             it->second.pop_back();
@@ -72,7 +74,7 @@ void *pool_alloc(size_t bytes)
         }
     }
     std::lock_guard<std::mutex> lk(P.mu);
-    P.live[p] = r;
+    P.live[p] = std::make_pair(dev, r);
     return p;
 }
 

@@ -210,7 +210,7 @@ struct Buf4<double> {
     }
 };
 
-constexpr int kSparseMax = 8;   // tiles with more stored values than this go to the wave-wide dense pass
+constexpr int kSparseMax = 8;   // tiles with more stored values than this go to the wave-wide dense pass (6 would fit 7 waves per SIMD -- 71 VGPRs instead of 83 -- but sends more tiles to the dense pass: 44 vs 35.7 us on the webbase-like matrix)
 constexpr int kInlineSlots = 2; // stored values of a tile handled in the streaming loop; the rest of a tile waits in a queue
                                 // (1, 2 and 3 measure the same within 2 %)
 constexpr int kDenseTrip = 8;   // dense tiles per trip of the wave-wide pass

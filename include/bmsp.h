@@ -153,7 +153,9 @@ int bmsp_matrix_compare_device(bmsp_matrix_t m, int64_t nnz, const int *d_rows, 
 
 /* bmSparse_SpMV<VI,VO>(A, v, u, batched)  -- src/bmSparse_SPMV.cu:191-230.   u = A * v
  * v: device, num_cols entries of A's dtype; u: device, num_rows entries (float for F32/F16, double for F64).
- * Asynchronous on `stream`; A is not modified.  Rows of empty block-rows are written as 0. */
+ * Asynchronous on `stream`; A is not modified.  Rows of empty block-rows are written as 0.
+ * One stream per handle at a time: the cached sweep plan holds the hub rows' carry slots and arrival counters, so two sweeps of the
+ * SAME handle must not be in flight on different streams (different handles may). */
 int bmsp_spmv(bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *stream);
 
 /* SURVEY 8(f)3 -- Y = A * X for k vectors at once (what the reference's unfinished `batched` path points at,
