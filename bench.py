@@ -566,6 +566,15 @@ def cpu_baseline(wl, eff_bytes, args):
         dt, iters = time_cpu(lambda: O.csr_spmv(Ac, xc, t), budget * 0.08, min_iters=10)
         legs[name] = {"GBs": round(cb / dt / 1e9, 2), "gflops": round(2.0 * Ac.nnz / dt / 1e9, 2), "ms": round(dt * 1e3, 4), "iterations": iters,
                       "threads": t}
+    # the PRODUCT's host path for the same class (CSRMatrix::multiply_host -> bmsp_csr_spmv_host; no GPU call), next to the oracle's port
+    try:
+        import pybmsp as B
+        Pc = B.CSRMatrix.from_arrays(cn, cn, Ac.row_offsets, Ac.cols, Ac.vals)
+        dt, iters = time_cpu(lambda: Pc.spmv_host(xc, th), budget * 0.06, min_iters=10)
+        legs["product_host_path"] = {"GBs": round(cb / dt / 1e9, 2), "gflops": round(2.0 * Ac.nnz / dt / 1e9, 2), "ms": round(dt * 1e3, 4), "iterations": iters,
+                                     "threads": th, "entry": "bmsp_csr_spmv_host"}
+    except Exception as e:
+        legs["product_host_path"] = {"error": str(e)[:120]}
     out["cant_like"] = {"workload": "configs[0] stand-in: cusp::multiply CSR SpMV, host only, banded(62451, half_bw=32): %d nnz (cant: 62 451 rows, "
                                     "4 007 383 nnz)" % Ac.nnz, **legs}
     if not args.skip_spgemm:

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <memory>
 #include <numeric>
+#include <omp.h>
 #include <vector>
 
 namespace bmsp {
@@ -705,6 +706,92 @@ int bmsp_csr_spmv(bmsp_csr_t A, const float *x, float *y)
     if (A->num_cols) BMSP_HIP(hipMemcpy(dx.p, x, 4 * (size_t)A->num_cols, hipMemcpyHostToDevice));
     spmv(dA, dx.p, dy.p, BMSP_SPMV_DEFAULT, nullptr);
     if (A->num_rows) BMSP_HIP(hipMemcpy(y, dy.p, 4 * (size_t)A->num_rows, hipMemcpyDeviceToHost));
+    BMSP_API_END
+}
+
+// ---- the host path of class CSRMatrix (configs[0]: "cusp::multiply ..., host CPU path"): the reference's CSRMatrix wraps a
+// cusp::csr_matrix<int,float,host_memory> (include/CSRMatrix.h:20), i.e. cusp::multiply runs on the host.  These two follow the
+// host algorithms' contracts -- y[i] = sum over the row in column order, accumulator initialised to 0
+// (cusp/system/detail/sequential/multiply/csr_spmv.h:56-73; rows in parallel: omp/detail/multiply/csr_spmv.h:67-85); row-wise
+// Gustavson product in two passes, numeric zeros dropped by the sequential form (sequential/multiply/csr_spgemm.h:39-157) -- with
+// `threads` host threads (0 = all).  No GPU call is made.
+int bmsp_csr_spmv_host(bmsp_csr_t A, const float *x, float *y, int threads)
+{
+    BMSP_API_BEGIN
+    need(A, "A"); need(x, "x"); need(y, "y");
+    const int nr = A->num_rows;
+    const int *ro = A->row_offsets.data(), *ci = A->cols.data();
+    const float *va = A->vals.data();
+    const int nt = threads > 0 ? threads : omp_get_max_threads();
+    (void)nt;
+    // rows in parallel, each row summed in column order (omp/detail/multiply/csr_spmv.h:67-85)
+#pragma omp parallel for num_threads(nt) schedule(static, 512) if (nt > 1 && nr >= 4096)
+    for (int i = 0; i < nr; i++) {
+        float sum = 0.0f;
+        for (int jj = ro[i]; jj < ro[i + 1]; jj++) sum += va[jj] * x[ci[jj]];
+        y[i] = sum;
+    }
+    BMSP_API_END
+}
+
+int bmsp_csr_multiply_host(bmsp_csr_t A, bmsp_csr_t B, bmsp_csr_t *C, int threads)
+{
+    BMSP_API_BEGIN
+    need(A, "A"); need(B, "B"); need(C, "C");
+    if (A->num_cols != B->num_rows) fail(BMSP_ERR_INVALID, "shape mismatch");
+    const int nr = A->num_rows, nc = B->num_cols;
+    const int nt = std::max(1, std::min(threads > 0 ? threads : omp_get_max_threads(), std::max(1, nr / 256)));
+    std::unique_ptr<bmsp_csr_s> m(new bmsp_csr_s());
+    m->num_rows = nr; m->num_cols = nc;
+    m->row_offsets.assign((size_t)nr + 1, 0);
+    std::vector<std::vector<int>> t_cols((size_t)nt);
+    std::vector<std::vector<float>> t_vals((size_t)nt);
+    std::vector<int> bounds((size_t)nt + 1, nr);
+    bounds[0] = 0;
+    {
+        const int64_t nnz = A->row_offsets[(size_t)nr];
+        for (int t = 1; t < nt; t++)
+            bounds[(size_t)t] = std::max(bounds[(size_t)t - 1], (int)(std::upper_bound(A->row_offsets.begin(), A->row_offsets.end(), (int)(nnz * t / nt)) - A->row_offsets.begin()));
+        for (int t = 1; t < nt; t++) bounds[(size_t)t] = std::min(bounds[(size_t)t], nr);
+    }
+    auto work = [&](int t) {
+        // Gustavson with a linked list of touched columns (spmm_csr_pass2, csr_spgemm.h:79-157); numeric zeros are not stored (:135)
+        std::vector<int> next((size_t)nc, -1);
+        std::vector<float> sums((size_t)nc, 0.0f);
+        std::vector<int> &oc = t_cols[(size_t)t];
+        std::vector<float> &ov = t_vals[(size_t)t];
+        for (int i = bounds[(size_t)t]; i < bounds[(size_t)t + 1]; i++) {
+            int head = -2, length = 0;
+            for (int jj = A->row_offsets[(size_t)i]; jj < A->row_offsets[(size_t)i + 1]; jj++) {
+                const int j = A->cols[(size_t)jj];
+                const float v = A->vals[(size_t)jj];
+                for (int kk = B->row_offsets[(size_t)j]; kk < B->row_offsets[(size_t)j + 1]; kk++) {
+                    const int k = B->cols[(size_t)kk];
+                    sums[(size_t)k] += v * B->vals[(size_t)kk];
+                    if (next[(size_t)k] == -1) { next[(size_t)k] = head; head = k; length++; }
+                }
+            }
+            int kept = 0;
+            for (int q = 0; q < length; q++) {
+                if (sums[(size_t)head] != 0.0f) { oc.push_back(head); ov.push_back(sums[(size_t)head]); kept++; }
+                const int tmp = head;
+                head = next[(size_t)head];
+                next[(size_t)tmp] = -1;
+                sums[(size_t)tmp] = 0.0f;
+            }
+            m->row_offsets[(size_t)i + 1] = kept;
+        }
+    };
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+    for (int t = 0; t < nt; t++) work(t);
+    for (int i = 0; i < nr; i++) m->row_offsets[(size_t)i + 1] += m->row_offsets[(size_t)i];
+    m->cols.reserve((size_t)m->row_offsets[(size_t)nr]);
+    m->vals.reserve((size_t)m->row_offsets[(size_t)nr]);
+    for (int t = 0; t < nt; t++) {
+        m->cols.insert(m->cols.end(), t_cols[(size_t)t].begin(), t_cols[(size_t)t].end());
+        m->vals.insert(m->vals.end(), t_vals[(size_t)t].begin(), t_vals[(size_t)t].end());
+    }
+    *C = m.release();
     BMSP_API_END
 }
 

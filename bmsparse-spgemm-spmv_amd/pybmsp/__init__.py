@@ -31,7 +31,7 @@ SYMBOLS = [
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
     "bmsp_comm_unique_id", "bmsp_comm_init", "bmsp_comm_init_from_env", "bmsp_comm_info", "bmsp_comm_free", "bmsp_spgemm_sharded", "bmsp_spmv_sharded",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
-    "bmsp_csr_spmv", "bmsp_csr_free",
+    "bmsp_csr_spmv", "bmsp_csr_multiply_host", "bmsp_csr_spmv_host", "bmsp_csr_free",
 ]
 
 
@@ -127,6 +127,8 @@ def lib():
         L.bmsp_csr_arrays.argtypes = [vp, p(vp), p(vp), p(vp)]
         L.bmsp_csr_multiply.argtypes = [vp, vp, p(vp)]
         L.bmsp_csr_spmv.argtypes = [vp, vp, vp]
+        L.bmsp_csr_multiply_host.argtypes = [vp, vp, p(vp), i]
+        L.bmsp_csr_spmv_host.argtypes = [vp, vp, vp, i]
         L.bmsp_csr_free.argtypes = [vp]
         _lib = L
     return _lib
@@ -524,6 +526,19 @@ class CSRMatrix:
         h = C.c_void_p()
         check(lib().bmsp_csr_multiply(self.h, other.h, C.byref(h)))
         return CSRMatrix(h.value)
+
+    def multiply_host(self, other, threads=0):
+        """cusp::multiply's host path (no GPU call)."""
+        h = C.c_void_p()
+        check(lib().bmsp_csr_multiply_host(self.h, other.h, C.byref(h), int(threads)))
+        return CSRMatrix(h.value)
+
+    def spmv_host(self, x, threads=0):
+        nr = self.arrays()[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty(nr, dtype=np.float32)
+        check(lib().bmsp_csr_spmv_host(self.h, x.ctypes.data, y.ctypes.data, int(threads)))
+        return y
 
     def spmv(self, x):
         nr = self.arrays()[0]

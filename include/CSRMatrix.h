@@ -53,6 +53,22 @@ public:
         check(bmsp_csr_spmv(h_, x.data(), y.data()));
         return y;
     }
+    /* the reference's own path: cusp::multiply on the host container (no GPU involved); `threads` = 0 uses every core */
+    CSRMatrix multiply_host(CSRMatrix matrix, int threads = 0)
+    {
+        bmsp_csr_t c = nullptr;
+        check(bmsp_csr_multiply_host(h_, matrix.h_, &c, threads));
+        return CSRMatrix(c);
+    }
+    std::vector<float> multiply_host(const std::vector<float> &x, int threads = 0)
+    {
+        int nr, nc; int64_t nnz;
+        check(bmsp_csr_info(h_, &nr, &nc, &nnz));
+        if ((int)x.size() != nc) throw std::runtime_error("CSRMatrix::multiply_host: vector length mismatch");
+        std::vector<float> y((size_t)nr);
+        check(bmsp_csr_spmv_host(h_, x.data(), y.data(), threads));
+        return y;
+    }
     bmsp_host_csr<int, float> host() const
     {
         bmsp_host_csr<int, float> m;

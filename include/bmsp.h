@@ -268,6 +268,12 @@ int bmsp_csr_info(bmsp_csr_t m, int *num_rows, int *num_cols, int64_t *nnz);
 int bmsp_csr_arrays(bmsp_csr_t m, const int **row_offsets, const int **cols, const float **vals);
 int bmsp_csr_multiply(bmsp_csr_t A, bmsp_csr_t B, bmsp_csr_t *C);            /* CSRMatrix::multiply */
 int bmsp_csr_spmv(bmsp_csr_t A, const float *x, float *y);
+/* The HOST forms of the two (the reference's CSRMatrix holds a cusp host matrix, so its multiply is cusp's host path --
+ * cusp/system/detail/sequential/multiply/csr_spmv.h:56-73, csr_spgemm.h:39-157 and the omp variants): no GPU call is made; `threads`
+ * host threads (0 = all).  The product's columns come out in the list order of the Gustavson accumulator (unsorted within a row,
+ * csr_spgemm.h:153), numeric zeros dropped. */
+int bmsp_csr_multiply_host(bmsp_csr_t A, bmsp_csr_t B, bmsp_csr_t *C, int threads);
+int bmsp_csr_spmv_host(bmsp_csr_t A, const float *x, float *y, int threads);
 int bmsp_csr_free(bmsp_csr_t m);
 
 #ifdef __cplusplus

@@ -62,6 +62,13 @@ int main(int argc, char **argv)
         double scsr = 0;
         for (float f : hc.values) scsr += f;
         std::printf("CHECK csr %zu %zu %g\n", hc.num_rows, hc.num_entries, scsr);
+        // the reference's own path for this class: cusp::multiply on the host container
+        const bmsp_host_csr<int, float> hh = ca.multiply_host(cb, 2).host();
+        double shost = 0;
+        for (float f : hh.values) shost += f;
+        double sy = 0;
+        for (float f : ca.multiply_host(std::vector<float>(hh.num_cols, 1.0f))) sy += f;
+        std::printf("CHECK csr_host %zu %zu %g %g\n", hh.num_rows, hh.num_entries, shost, sy);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

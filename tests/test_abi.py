@@ -131,3 +131,45 @@ def test_parallel_parser_matches_python_float(bmsp, tmp_path, monkeypatch):
     open(path, "w").write("".join(lines + ["1 1 1.0\n"]))
     with pytest.raises(bmsp.BmspError):
         bmsp.CSRMatrix.from_mtx(path)
+
+
+def test_csr_host_path_matches_cusp_semantics(bmsp, oracle):
+    """configs[0]: CSRMatrix's host path (bmsp_csr_spmv_host / bmsp_csr_multiply_host, no GPU call) on the reference-held fixtures
+    and the cusp multiply.cu known answers: SpMV bit-identical with the oracle's restatement of csr_spmv.h:56-73 (same summation
+    order), products equal the dense product and drop numeric zeros like csr_spgemm.h:135; 1 thread and several."""
+    import json
+    from conftest import GOLDEN
+    for rel in ("laplacian/5pt_10x10.mtx", "laplacian/7pt_10x10x10.mtx", "random_10x10/030_nonzeros.mtx", "random_10x10/000_nonzeros.mtx", "real/A_matrix.mtx"):
+        path = os.path.join(MTX, rel)
+        m = bmsp.CSRMatrix.from_mtx(path)
+        nr, nc, ro, cols, vals = m.arrays()
+        ref = oracle.csr_from_coo(oracle.mtx_read(path, strict=True))
+        x = (np.arange(nc) % 10).astype(np.float32)
+        want = oracle.csr_spmv(ref, x, 1)
+        for th in (1, 3):
+            np.testing.assert_array_equal(m.spmv_host(x, th).view(np.uint32), want.view(np.uint32))
+        if nr == nc:
+            dense = np.zeros((nr, nc))
+            for i in range(nr):
+                dense[i, cols[ro[i]:ro[i + 1]]] = vals[ro[i]:ro[i + 1]]
+            for th in (1, 4):
+                c = m.multiply_host(m, th)
+                cr, cc, cro, ccols, cvals = c.arrays()
+                got = np.zeros((cr, cc))
+                for i in range(cr):
+                    assert len(set(ccols[cro[i]:cro[i + 1]].tolist())) == cro[i + 1] - cro[i]
+                    got[i, ccols[cro[i]:cro[i + 1]]] = cvals[cro[i]:cro[i + 1]]
+                np.testing.assert_array_equal(got, dense @ dense)
+                assert not np.any(cvals == 0.0)
+    g = json.load(open(os.path.join(GOLDEN, "cusp_multiply.json")))
+    import scipy.sparse as sp
+    for pr in g["products"]:
+        L = np.asarray(g["matrices"][pr["left"]]["dense"], dtype=np.float32)
+        R = np.asarray(g["matrices"][pr["right"]]["dense"], dtype=np.float32)
+        la, ra = sp.csr_matrix(L), sp.csr_matrix(R)
+        la.sort_indices(); ra.sort_indices()
+        a = bmsp.CSRMatrix.from_arrays(L.shape[0], L.shape[1], la.indptr, la.indices, la.data)
+        b = bmsp.CSRMatrix.from_arrays(R.shape[0], R.shape[1], ra.indptr, ra.indices, ra.data)
+        cr, cc, cro, ccols, cvals = a.multiply_host(b, 2).arrays()
+        got = sp.csr_matrix((cvals, ccols, cro), shape=(cr, cc)).toarray().astype(np.float64)
+        np.testing.assert_array_equal(got, np.asarray(pr["dense"], dtype=np.float64))

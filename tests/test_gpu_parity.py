@@ -1037,6 +1037,8 @@ def test_cpp_api_surface(tmp_path, bmsp):
     Cm = bmsp.CSRMatrix.from_mtx(os.path.join(folder, "A_matrix.mtx")).multiply(bmsp.CSRMatrix.from_mtx(os.path.join(folder, "B_matrix.mtx")))
     nr, nc, ro, cols, vals = Cm.arrays()
     assert [int(lines["csr"][0]), int(lines["csr"][1])] == [nr, len(cols)] and float(lines["csr"][2]) == float(np.sum(vals.astype(np.float64)))
+    # CSRMatrix's host path (cusp::multiply on the host container): same product, no GPU call; y = A*1 sums to 109
+    assert [int(lines["csr_host"][0]), int(lines["csr_host"][1])] == [nr, len(cols)] and float(lines["csr_host"][2]) == 1070.0 and float(lines["csr_host"][3]) == 109.0
 
 
 def test_cli_executables_and_batch_scripts(tmp_path):
