@@ -549,16 +549,18 @@ __global__ __launch_bounds__(kThreads) void spmv_rowgroup_kernel(const uint32_t 
         uint32_t t = valid ? rowptr[br] : 0u;
         const uint32_t t1 = valid ? rowptr[br + 1] : 0u;
         A acc = 0;
-        while (__any(t < t1)) {
-            uint32_t blo[U], bhi[U], col[U], off[U];
+        // tile words of the first trip; inside the loop the NEXT trip's words are requested behind the current trip's value / x
+        // loads, so a trip waits for one round trip (its values), not two
+        uint32_t blo[U], bhi[U], col[U], off[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const bool on = t + u < t1;
-                const uint64_t bm = on ? bmps[t + u] : 0ull;
-                blo[u] = (uint32_t)bm; bhi[u] = (uint32_t)(bm >> 32);
-                col[u] = on ? (uint32_t)keys[t + u] : 0u;
-                off[u] = on ? (uint32_t)offsets[t + u] : 0u;
-            }
+        for (int u = 0; u < U; u++) {
+            const bool on = t + u < t1;
+            const uint64_t bm = on ? bmps[t + u] : 0ull;
+            blo[u] = (uint32_t)bm; bhi[u] = (uint32_t)(bm >> 32);
+            col[u] = on ? (uint32_t)keys[t + u] : 0u;
+            off[u] = on ? (uint32_t)offsets[t + u] : 0u;
+        }
+        while (__any(t < t1)) {
             A av[U][4], xv[U][4];
             uint32_t nib[U];
 #pragma unroll
@@ -585,6 +587,15 @@ __global__ __launch_bounds__(kThreads) void spmv_rowgroup_kernel(const uint32_t 
                     Buf4<T>::ld(rx, nib[u] ? xc * (uint32_t)sizeof(T) : kOob, xv[u]);
                 }
             }
+            uint32_t nlo[U], nhi[U], ncol[U], noff[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool on = t + U + u < t1;
+                const uint64_t bm = on ? bmps[t + U + u] : 0ull;
+                nlo[u] = (uint32_t)bm; nhi[u] = (uint32_t)(bm >> 32);
+                ncol[u] = on ? (uint32_t)keys[t + U + u] : 0u;
+                noff[u] = on ? (uint32_t)offsets[t + U + u] : 0u;
+            }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t n = nib[u];
@@ -604,6 +615,8 @@ __global__ __launch_bounds__(kThreads) void spmv_rowgroup_kernel(const uint32_t 
                 acc += e0 * xv[u][0] + e1 * xv[u][1] + e2 * xv[u][2] + e3 * xv[u][3];
             }
             t += U;
+#pragma unroll
+            for (int u = 0; u < U; u++) { blo[u] = nlo[u]; bhi[u] = nhi[u]; col[u] = ncol[u]; off[u] = noff[u]; }
         }
         // lanes 2r and 2r+1 hold the two halves of tile row r
         if (sizeof(A) == 4) acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)acc), 0xB1, 0xf, 0xf, false));  // quad_perm 1,0,3,2
@@ -640,7 +653,8 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
         if ((variant == 3 || (variant == BMSP_SPMV_DEFAULT && dense_tiles && A->spmv_plan_long == 0 && !getenv("BMSP_SPMV_NO_ROWGROUP"))) && pool_owns(A->values)) {
             constexpr int U = 3;
             const uint32_t groups = (nbr + 3) / 4;
-            const uint32_t passes = groups > 32768 ? 2u : 1u;
+            const char *pe = getenv("BMSP_SPMV_PASSES");
+            const uint32_t passes = pe ? (uint32_t)std::max(1, atoi(pe)) : (groups > 32768 ? 2u : 1u);
             const uint32_t waves = (groups + passes - 1) / passes;
             hipLaunchKernelGGL((spmv_rowgroup_kernel<T, U>), dim3((waves + 3) / 4), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps, A->offsets,
                                (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows, (uint32_t)A->num_cols, nbr,
