@@ -423,11 +423,18 @@ void host_slot_release(void *p);
 template <typename T>
 struct HostScalar {
     T *p;
-    // all-ones = "not written yet": no count or packed total of this library reaches it
+    mutable bool done = false;  // wait() has returned: the producing kernel's store has landed
+    // all-ones = "not written yet": a genuine all-ones value only costs the 200 us poll before the stream synchronise below confirms it
     HostScalar() : p(static_cast<T *>(host_slot_acquire())) { *(volatile T *)p = ~T(0); }
     HostScalar(const HostScalar &) = delete;
     HostScalar &operator=(const HostScalar &) = delete;
-    ~HostScalar() { host_slot_release(p); }
+    ~HostScalar()
+    {
+        // unwinding (an exception between the launch and wait()) with the producer possibly still in flight: the slot must not go
+        // back to the pool while a kernel may still write it -- the next user would read that stale store as its own result
+        if (!done) (void)hipDeviceSynchronize();
+        host_slot_release(p);
+    }
     T *dev() const { return p; }  // device-accessible address
     // The producing kernel stores the scalar with one aligned store into coherent host memory, so the host can pick it up as
     // soon as it lands instead of waiting for the kernel to drain and the queue to signal (~19 us of idle GPU per read-back on
@@ -442,6 +449,7 @@ struct HostScalar {
                 break;
             }
         }
+        done = true;
         return *(volatile T *)p;
     }
 };

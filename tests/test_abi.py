@@ -173,3 +173,19 @@ def test_csr_host_path_matches_cusp_semantics(bmsp, oracle):
         cr, cc, cro, ccols, cvals = a.multiply_host(b, 2).arrays()
         got = sp.csr_matrix((cvals, ccols, cro), shape=(cr, cc)).toarray().astype(np.float64)
         np.testing.assert_array_equal(got, np.asarray(pr["dense"], dtype=np.float64))
+
+
+def test_comm_rendezvous_argument_errors(bmsp, monkeypatch):
+    """bmsp_comm_init_from_env / bmsp_comm_init reject bad rendezvous settings before RCCL is touched (runs without a GPU)."""
+    import ctypes
+    h = ctypes.c_void_p()
+    monkeypatch.delenv("BMSP_WORLD", raising=False)
+    monkeypatch.delenv("BMSP_RANK", raising=False)
+    assert bmsp.lib().bmsp_comm_init_from_env(ctypes.byref(h)) == -1 and b"BMSP_WORLD" in bmsp.lib().bmsp_last_error()
+    monkeypatch.setenv("BMSP_WORLD", "4"); monkeypatch.setenv("BMSP_RANK", "7")
+    assert bmsp.lib().bmsp_comm_init_from_env(ctypes.byref(h)) == -1 and b"outside" in bmsp.lib().bmsp_last_error()
+    monkeypatch.setenv("BMSP_RANK", "1"); monkeypatch.delenv("BMSP_COMM_FILE", raising=False)
+    assert bmsp.lib().bmsp_comm_init_from_env(ctypes.byref(h)) == -1 and b"BMSP_COMM_FILE" in bmsp.lib().bmsp_last_error()
+    with pytest.raises(bmsp.BmspError):
+        bmsp.Comm(b"\0" * 128, 2, 5)
+    assert bmsp.lib().bmsp_comm_free(None) == 0
