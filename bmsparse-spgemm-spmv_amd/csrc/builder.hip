@@ -374,6 +374,7 @@ void free_matrix(bmsp_matrix_s *m)
     }
     pool_free(m->rowptr);
     pool_free(m->spmv_chunks);
+    pool_free(m->spmv_pos);
     pool_free(m->block_meta);
     pool_free(m->dense_tiles);
     free_matrix(m->shard_view);

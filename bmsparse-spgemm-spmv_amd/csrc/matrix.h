@@ -26,6 +26,10 @@ struct bmsp_matrix_s {
     int64_t spmv_plan_long = 0;
     int64_t spmv_full_tiles = 0;  // tiles with all 64 values stored (decides the sweep variant)
     size_t spmv_plan_off_cnt = 0, spmv_plan_off_carry = 0;
+    // position cache of the value-stream SpMV: one 16-bit {tile slot in its batch, position in the tile} entry per stored value
+    uint16_t *spmv_pos = nullptr;
+    int64_t spmv_pos_base = 0, spmv_pos_count = 0;
+    int spmv_pos_tried = 0;
     // (bitmap, value offset) of every block as one 16-byte record, for kernels that gather both (block-MAC): built lazily
     uint32_t *block_meta = nullptr;  // block_num x {bmp lo, bmp hi, offset in elements, 0}
     // fp16 matrices: every tile expanded to 64 halves in position order (128 B per block), for the K = 32 MFMA block-MAC: built lazily

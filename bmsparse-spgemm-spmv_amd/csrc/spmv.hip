@@ -38,6 +38,13 @@
 namespace bmsp {
 namespace {
 
+constexpr uint32_t kVsGroup = 96;  // plan granularity for the value-stream kernel: most items are one 128-tile batch
+// the value-stream kernel takes matrices whose tiles are mostly sparse (full tiles go to the FULL sweep / the row-group kernel)
+bool vstream_eligible(const bmsp_matrix_s *A)
+{
+    return !(A->spmv_full_tiles * 4 >= A->block_num) && !getenv("BMSP_SPMV_OLD") && A->num_block_cols() < (1ll << 28);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // plan construction (once per matrix)
 // ---------------------------------------------------------------------------------------------------------
@@ -45,11 +52,12 @@ struct RowClass {
     const uint32_t *rowptr;
     const uint64_t *offsets;
     uint32_t nbr;
+    uint32_t group;  // short block-rows are grouped up to the next multiple of `group` tiles
     __device__ bool is_long(uint32_t r) const { return rowptr[r + 1] - rowptr[r] > kItemTiles; }
     __device__ bool starts(uint32_t r) const
     {
         if (r == 0 || (r % kItemRows) == 0) return true;
-        if (rowptr[r] / kItemTiles != rowptr[r - 1] / kItemTiles) return true;
+        if (rowptr[r] / group != rowptr[r - 1] / group) return true;
         return is_long(r) || is_long(r - 1);
     }
     // packed counts: low 36 bits = items contributed by row r, high bits = 1 if long
@@ -86,13 +94,13 @@ struct PlanFill {
         const uint32_t base = (uint32_t)(ex & ((1ull << 36) - 1)), lbase = (uint32_t)(ex >> 36);
         const uint32_t r = (uint32_t)r64;
         if (r == rc.nbr) {
-            if (rc.nbr && !rc.is_long(rc.nbr - 1)) { items[base - 1].row_end = rc.nbr; items[base - 1].blk_end = nb; }
+            if (rc.nbr && !rc.is_long(rc.nbr - 1)) { items[base - 1].row_end = rc.nbr; items[base - 1].blk_end = nb; items[base - 1].first_item = (uint32_t)rc.offsets[nb]; }
             return;
         }
         const bool lg = rc.is_long(r), st = lg || rc.starts(r);
         if (!st) return;
         const uint32_t s = rc.rowptr[r], e = rc.rowptr[r + 1];
-        if (r > 0 && !rc.is_long(r - 1)) { items[base - 1].row_end = r; items[base - 1].blk_end = s; }
+        if (r > 0 && !rc.is_long(r - 1)) { items[base - 1].row_end = r; items[base - 1].blk_end = s; items[base - 1].first_item = (uint32_t)rc.offsets[s]; }
         if (lg) {
             const uint32_t cnt = (e - s + kItemTiles - 1) / kItemTiles;
             for (uint32_t c = 0; c < cnt; c++) {
@@ -100,12 +108,12 @@ struct PlanFill {
                 it.row_begin = r; it.row_end = r + 1;
                 it.blk_begin = s + c * kItemTiles;
                 it.blk_end = min(e, s + (c + 1) * kItemTiles);
-                it.first_item = base; it.num_items = cnt; it.long_idx = lbase; it.pad = 0;
+                it.first_item = base; it.num_items = cnt; it.long_idx = lbase; it.val_begin = (uint32_t)rc.offsets[it.blk_begin];
                 items[base + c] = it;
             }
         } else {
             items[base].row_begin = r; items[base].blk_begin = s;
-            items[base].first_item = base; items[base].num_items = 0; items[base].long_idx = 0xffffffffu; items[base].pad = 0;
+            items[base].num_items = 0; items[base].long_idx = 0xffffffffu; items[base].val_begin = (uint32_t)rc.offsets[s];
         }
     }
 };
@@ -124,7 +132,12 @@ void build_plan(bmsp_matrix_s *A, hipStream_t st)
     if (A->spmv_chunks) return;
     ensure_rowptr(A, st);
     const uint32_t nbr = (uint32_t)A->num_block_rows(), nb = (uint32_t)A->block_num;
-    RowClass rc{A->rowptr, A->offsets, nbr};
+    HostScalar<uint64_t> full_h;
+    device_exclusive_scan<uint64_t>(FullTileIn{A->bmps, nb}, PlanTotals{nb, full_h.dev()}, (uint64_t)nb + 1, st);
+    A->spmv_full_tiles = (int64_t)full_h.wait(st);
+    // short block-rows are grouped up to the next multiple of `group` tiles: one 128-tile batch for the value-stream kernel
+    const char *ge = getenv("BMSP_SPMV_GROUP");
+    RowClass rc{A->rowptr, A->offsets, nbr, ge ? (uint32_t)std::max(16, atoi(ge)) : (vstream_eligible(A) ? kVsGroup : kItemTiles)};
     DevBuf<uint64_t> tot(1);
     device_exclusive_scan<uint64_t>(rc, PlanTotals{nbr, tot.p}, (uint64_t)nbr + 1, st);
     const uint64_t packed = read_back(tot.p, st);
@@ -139,9 +152,6 @@ void build_plan(bmsp_matrix_s *A, hipStream_t st)
     uint32_t hdr[4] = {n_items, n_long, (uint32_t)off_cnt, (uint32_t)off_carry};
     BMSP_HIP(hipMemcpyAsync(mem, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
     if (nbr) device_exclusive_scan<uint64_t>(rc, PlanFill{rc, nb, (SweepItem *)(mem + off_items)}, (uint64_t)nbr + 1, st);
-    HostScalar<uint64_t> full_h;
-    device_exclusive_scan<uint64_t>(FullTileIn{A->bmps, nb}, PlanTotals{nb, full_h.dev()}, (uint64_t)nb + 1, st);
-    A->spmv_full_tiles = (int64_t)full_h.wait(st);
     A->spmv_chunks = (uint32_t *)mem;
     A->spmv_num_chunks = n_items;
     A->spmv_plan_long = n_long;
@@ -209,6 +219,11 @@ struct Buf4<double> {
         o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1];
     }
 };
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+}
 
 constexpr int kSparseMax = 8;   // tiles with more stored values than this go to the wave-wide dense pass (6 would fit 7 waves per SIMD -- 71 VGPRs instead of 83 -- but sends more tiles to the dense pass: 44 vs 35.7 us on the webbase-like matrix)
 constexpr int kInlineSlots = 2; // stored values of a tile handled in the streaming loop; the rest of a tile waits in a queue
@@ -466,6 +481,327 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, 8
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// value-stream sweep (round 2; the default for matrices whose tiles are mostly sparse)
+// ---------------------------------------------------------------------------------------------------------
+// Same plan, same items, same epilogue as the sweep above, but the elements are walked LANE PER STORED VALUE instead of lane per tile:
+//   1. lane-per-tile: the tile words of up to 128 tiles (two per lane, coalesced); the batch is the longest run of those tiles that holds
+//      at most 512 stored values;
+//   2. every stored value has a 16-bit ENTRY {tile slot in the batch, position in the tile} at its index inside the batch.  kDecode
+//      builds the entries in LDS from the bitmaps (a loop of max-popcount trips over the tile lanes: 36 % of the kernel's VALU work on
+//      the webbase-like matrix, 52 % on the cage-like one).  kCached reads them from the POSITION CACHE -- the same entries, written
+//      once per matrix by kBuild into a 2-byte-per-value array that sits beside the values (part of the cached SpMV plan, like the
+//      block-row pointer and the items; bmsp_matrix_prepare builds it, BMSP_SPMV_NO_POSCACHE=1 or a cache above BMSP_SPMV_POSCACHE_MAX
+//      bytes keeps the decode in the kernel).  With the cache the bitmaps are not read at all: keys + next offsets + entries + values.
+//   3. lane-per-value: value v is ONE coalesced load of the value array (no value gather), its x entry one gather with every lane busy.
+//   4. reduction into the item's u tile in LDS.  kAtomic: ds_add_f32 -- 3 cycles per active lane on gfx950
+//      (experiments/lds_atomic_rate.hip), affordable at < 2 values per tile.  kSorted: the products are counting-sorted by row with
+//      INTEGER LDS atomics (full rate), run sums are taken with DPP steps, the last lane of a run adds to the tile with a plain
+//      read-modify-write.
+constexpr uint32_t kVsTiles = 128;  // tiles per batch at most (two per lane)
+constexpr uint32_t kVsVals = 512;   // values per batch at most
+constexpr int kVsChunks = kVsVals / 64;
+enum { kDecode = 0, kCached = 1, kBuild = 2 };
+enum { kAtomic = 0, kSorted = 1 };
+
+// lane i receives `src` of the lane the DPP control names; lanes without a source (or outside ROW_MASK) keep `old`
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_val(float old, float src)
+{
+    return __builtin_bit_cast(float, dpp_u32<CTRL, ROW_MASK>(__builtin_bit_cast(uint32_t, old), __builtin_bit_cast(uint32_t, src)));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_val(double old, double src)
+{
+    const uint64_t o = __builtin_bit_cast(uint64_t, old), v = __builtin_bit_cast(uint64_t, src);
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)o, (uint32_t)v), hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(o >> 32), (uint32_t)(v >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// inclusive sums over runs of equal `key` in lane order (keys are sorted, so equal keys d lanes apart mean one run)
+template <typename A>
+__device__ __forceinline__ A wave_run_sum(A v, uint32_t key)
+{
+#define BMSP_RUN_STEP(CTRL, RM)                                   \
+    {                                                             \
+        const A pv = dpp_val<CTRL, RM>(A(0), v);                  \
+        const uint32_t pk = dpp_u32<CTRL, RM>(0xffffffffu, key);  \
+        v += pk == key ? pv : A(0);                               \
+    }
+    BMSP_RUN_STEP(0x111, 0xf)  // row_shr:1
+    BMSP_RUN_STEP(0x112, 0xf)  // row_shr:2
+    BMSP_RUN_STEP(0x114, 0xf)  // row_shr:4
+    BMSP_RUN_STEP(0x118, 0xf)  // row_shr:8
+    BMSP_RUN_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1 and 3
+    BMSP_RUN_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2 and 3
+#undef BMSP_RUN_STEP
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t v)
+{
+    v += dpp_u32<0x111>(0, v);
+    v += dpp_u32<0x112>(0, v);
+    v += dpp_u32<0x114>(0, v);
+    v += dpp_u32<0x118>(0, v);
+    v += dpp_u32<0x142, 0xa>(0, v);
+    v += dpp_u32<0x143, 0xc>(0, v);
+    return v;
+}
+
+template <typename A, int MODE, int RED>
+struct VsLds {
+    // u tile (16 block-rows x 8) | tile slots | [row counters, then row starts] | [entries, then the products in row order] | [their rows]
+    static constexpr uint32_t tile = 0, tinfo = tile + kItemRows * 8 * sizeof(A), cnt = tinfo + kVsTiles * 4;
+    static constexpr uint32_t region = cnt + (RED == kSorted ? kItemRows * 8 * 4 : 0);
+    static constexpr uint32_t region_bytes = (RED == kSorted ? kVsVals * sizeof(A) : (MODE == kCached ? 0 : kVsVals * 2));
+    static constexpr uint32_t srow = region + region_bytes;
+    static constexpr uint32_t bytes = srow + (RED == kSorted ? kVsVals : 0);
+};
+
+template <typename T, int MODE, int RED>
+__global__ __launch_bounds__(64) void spmv_vstream_kernel(const SweepItem *__restrict__ items, uint32_t num_items,
+                                                          const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bmps,
+                                                          const uint64_t *__restrict__ offsets, const T *__restrict__ values,
+                                                          const T *__restrict__ x, typename Acc<T>::type *__restrict__ y,
+                                                          typename Acc<T>::type *__restrict__ carry, uint32_t *__restrict__ counters,
+                                                          uint32_t num_rows, uint32_t num_cols, uint32_t values_bytes,
+                                                          uint16_t *__restrict__ pos, uint32_t pos_base, uint32_t pos_count)
+{
+    using A = typename Acc<T>::type;
+    using L = VsLds<A, MODE, RED>;
+    // one wave per workgroup: a finished wave frees its slot and its LDS at once
+    __shared__ __attribute__((aligned(16))) unsigned char lds[L::bytes];
+    A *const tile = (A *)(lds + L::tile);
+    uint32_t *const tinfo = (uint32_t *)(lds + L::tinfo);
+    uint32_t *const cnt = (uint32_t *)(lds + L::cnt);
+    uint16_t *const ent = (uint16_t *)(lds + L::region);
+    A *const sorted = (A *)(lds + L::region);
+    uint8_t *const srow = lds + L::srow;
+    const int lane = lane_id();
+    const uint32_t item_id = blockIdx.x;
+    const SweepItem it = items[item_id];
+    const rsrc_t rv = make_rsrc(values, values_bytes), rx = make_rsrc(x, num_cols * (uint32_t)sizeof(T));
+    const rsrc_t rp = make_rsrc(pos, pos_count * 2u);
+    tile[lane] = A(0);
+    tile[64 + lane] = A(0);
+    // kCached: entries and values of the item's first 256 values are requested before its tile words are (their place is in the item)
+    constexpr int kPre = 4;
+    uint32_t pre_e[kPre];
+    A pre_a[kPre];
+    if (MODE == kCached) {
+        const uint32_t n_item = it.num_items == 0 ? it.first_item - it.val_begin : 64u * kPre;
+#pragma unroll
+        for (int u = 0; u < kPre; u++) {
+            const uint32_t idx = 64u * (uint32_t)u + (uint32_t)lane;
+            const bool on = idx < n_item;
+            pre_e[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rp, on ? (it.val_begin - pos_base + idx) * 2u : kOob, 0, 0);
+            pre_a[u] = Buf<T>::ld(rv, on ? (it.val_begin + idx) * (uint32_t)sizeof(T) : kOob);
+        }
+    }
+
+    for (uint32_t base = it.blk_begin; base < it.blk_end;) {
+        const bool first = MODE == kCached && base == it.blk_begin;
+        const uint32_t b0 = base + (uint32_t)lane, b1 = base + 64u + (uint32_t)lane;
+        const uint32_t bend = min(base + kVsTiles, it.blk_end);
+        uint64_t bm0 = 0, bm1 = 0, k0 = (uint64_t)it.row_begin << 32, k1 = k0;
+        uint32_t o0 = 0, o1 = 0, e0 = kOob, e1 = kOob;  // start / end of the tile's values, relative to the batch's first value
+        uint32_t v_first;
+        if (MODE == kCached) {
+            if (b0 < bend) { k0 = keys[b0]; e0 = (uint32_t)offsets[b0 + 1]; }
+            if (b1 < bend) { k1 = keys[b1]; e1 = (uint32_t)offsets[b1 + 1]; }
+            v_first = (uint32_t)offsets[base];
+            e0 -= v_first;
+            e1 -= v_first;
+        } else {
+            if (b0 < bend) { bm0 = bmps[b0]; k0 = keys[b0]; o0 = (uint32_t)offsets[b0]; }
+            if (b1 < bend) { bm1 = bmps[b1]; k1 = keys[b1]; o1 = (uint32_t)offsets[b1]; }
+            v_first = __builtin_amdgcn_readfirstlane(o0);
+            o0 -= v_first;
+            o1 -= v_first;
+            e0 = o0 + (uint32_t)__popcll(bm0);
+            e1 = o1 + (uint32_t)__popcll(bm1);
+        }
+        // the batch: tiles whose values end inside the first kVsVals values (a prefix: offsets ascend; >= 8 tiles, a tile holds <= 64)
+        const bool ok0 = b0 < bend && e0 <= kVsVals, ok1 = b1 < bend && e1 <= kVsVals;
+        const uint32_t n0 = (uint32_t)__popcll(__ballot(ok0)), n1 = (uint32_t)__popcll(__ballot(ok1));
+        const uint32_t nb = n0 + n1;
+        const uint32_t nvals = nb <= 64u ? (uint32_t)__builtin_amdgcn_readlane((int)e0, (int)(nb - 1u)) : (uint32_t)__builtin_amdgcn_readlane((int)e1, (int)(nb - 65u));
+        // tile slots: column and row-in-window of every tile of the batch
+        tinfo[lane] = key_col(k0) | ((key_row(k0) - it.row_begin) << 28);
+        tinfo[64 + lane] = key_col(k1) | ((key_row(k1) - it.row_begin) << 28);
+        if (RED == kSorted) {
+            cnt[lane] = 0;
+            cnt[64 + lane] = 0;
+        }
+        if (MODE != kCached) {
+            // entries from the bitmaps: {slot, position} of every stored value, at the value's index inside the batch
+            uint64_t m0 = ok0 ? bm0 : 0, m1 = ok1 ? bm1 : 0;
+            uint32_t i0 = o0, i1 = o1;
+            while (__any((m0 | m1) != 0)) {
+                if (m0) {
+                    const uint32_t p = (uint32_t)__clzll((long long)m0);
+                    m0 &= ~(0x8000000000000000ull >> p);
+                    ent[i0++] = (uint16_t)(((uint32_t)lane << 6) | p);
+                }
+                if (m1) {
+                    const uint32_t p = (uint32_t)__clzll((long long)m1);
+                    m1 &= ~(0x8000000000000000ull >> p);
+                    ent[i1++] = (uint16_t)(((64u + (uint32_t)lane) << 6) | p);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (MODE == kBuild) {
+            for (uint32_t idx = (uint32_t)lane; idx < nvals; idx += 64u) pos[v_first - pos_base + idx] = ent[idx];
+            __builtin_amdgcn_wave_barrier();
+            base += nb;
+            continue;
+        }
+        const uint32_t pos_first = (v_first - pos_base) * 2u;
+
+        if (RED == kAtomic) {
+            for (uint32_t c0 = 0; c0 < nvals; c0 += 256u) {
+                A av[4], xv[4];
+                uint32_t rowl[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t idx = c0 + 64u * (uint32_t)u + (uint32_t)lane;
+                    const bool on = idx < nvals;
+                    uint32_t e;
+                    if (first && c0 == 0) {
+                        e = pre_e[u];
+                        av[u] = pre_a[u];
+                    } else {
+                        e = MODE == kCached ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rp, on ? pos_first + idx * 2u : kOob, 0, 0) : (on ? (uint32_t)ent[idx] : 0u);
+                        av[u] = Buf<T>::ld(rv, on ? (v_first + idx) * (uint32_t)sizeof(T) : kOob);
+                    }
+                    const uint32_t ti = tinfo[e >> 6], p = e & 63u;
+                    rowl[u] = (ti >> 28) * 8u + (p >> 3);
+                    xv[u] = Buf<T>::ld(rx, on ? ((ti & 0x0fffffffu) * 8u + (p & 7u)) * (uint32_t)sizeof(T) : kOob);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (c0 + 64u * (uint32_t)u + (uint32_t)lane < nvals) lds_add(tile + rowl[u], av[u] * xv[u]);
+            }
+        } else {
+            // the value's rank among the values of its row: integer LDS counter
+            A prod[kVsChunks];
+            uint32_t rr[kVsChunks];  // row | rank << 8
+#pragma unroll
+            for (int u = 0; u < kVsChunks; u++) {
+                if (64u * (uint32_t)u < nvals) {
+                    const uint32_t idx = 64u * (uint32_t)u + (uint32_t)lane;
+                    const bool on = idx < nvals;
+                    uint32_t e;
+                    A av;
+                    if (first && u < kPre) {
+                        e = pre_e[u];
+                        av = pre_a[u];
+                    } else {
+                        e = MODE == kCached ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rp, on ? pos_first + idx * 2u : kOob, 0, 0) : (on ? (uint32_t)ent[idx] : 0u);
+                        av = Buf<T>::ld(rv, on ? (v_first + idx) * (uint32_t)sizeof(T) : kOob);
+                    }
+                    const uint32_t ti = tinfo[e >> 6], p = e & 63u;
+                    const uint32_t rowl = (ti >> 28) * 8u + (p >> 3);
+                    const A xv = Buf<T>::ld(rx, on ? ((ti & 0x0fffffffu) * 8u + (p & 7u)) * (uint32_t)sizeof(T) : kOob);
+                    uint32_t rank = 0;
+                    if (on) rank = __hip_atomic_fetch_add(&cnt[rowl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    rr[u] = rowl | (rank << 8);
+                    prod[u] = av * xv;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // row counters -> row starts (exclusive sums; lane l owns rows 2l and 2l+1)
+            {
+                const uint32_t c0 = cnt[2 * lane], c1 = cnt[2 * lane + 1];
+                const uint32_t ex = wave_inclusive_sum_dpp(c0 + c1) - (c0 + c1);
+                cnt[2 * lane] = ex;
+                cnt[2 * lane + 1] = ex + c0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // products into row order (the entries of kDecode live in the same bytes: all of them were read above)
+#pragma unroll
+            for (int u = 0; u < kVsChunks; u++) {
+                if (64u * (uint32_t)u < nvals) {
+                    if (64u * (uint32_t)u + (uint32_t)lane < nvals) {
+                        const uint32_t rowl = rr[u] & 0xffu, at = cnt[rowl] + (rr[u] >> 8);
+                        sorted[at] = prod[u];
+                        srow[at] = (uint8_t)rowl;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // run sums; the last lane of every run adds its sum to the u tile (one lane per row and chunk: no atomic)
+#pragma unroll
+            for (int u = 0; u < kVsChunks; u++) {
+                if (64u * (uint32_t)u < nvals) {
+                    const uint32_t idx = 64u * (uint32_t)u + (uint32_t)lane;
+                    const bool on = idx < nvals;
+                    const A sv = on ? sorted[idx] : A(0);
+                    const uint32_t row = on ? (uint32_t)srow[idx] : 0xfeu;
+                    const uint32_t nxt = (lane < 63 && idx + 1u < nvals) ? (uint32_t)srow[idx + 1u] : 0xffu;
+                    const A run = wave_run_sum(sv, row);
+                    if (on && nxt != row) tile[row] += run;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        base += nb;
+    }
+    if (MODE == kBuild) return;
+
+    if (it.num_items == 0) {
+        // short item: the wave owns u[row_begin*8, row_end*8)
+        const uint32_t n_out = (it.row_end - it.row_begin) * 8u, out0 = it.row_begin * 8u;
+        for (uint32_t e = lane; e < n_out; e += 64)
+            if (out0 + e < num_rows) y[out0 + e] = tile[e];
+        return;
+    }
+    // long row: park the partial sums, the last arriver folds them (same protocol as spmv_sweep_kernel)
+    if (lane < 8) __hip_atomic_store(&carry[(size_t)item_id * 8 + lane], tile[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(&counters[it.long_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != it.num_items - 1) return;
+    const int r = lane & 7, g = lane >> 3;
+    A sum = 0;
+    for (uint32_t c = g; c < it.num_items; c += 8)
+        sum += __hip_atomic_load(&carry[(size_t)(it.first_item + c) * 8 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) sum += __shfl_xor(sum, d, kWave);
+    const uint32_t row = it.row_begin * 8u + (uint32_t)r;
+    if (g == 0 && row < num_rows) y[row] = sum;
+    if (lane == 0) __hip_atomic_store(&counters[it.long_idx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the position cache: kBuild pass over the plan's items, once per matrix
+void build_pos_cache(bmsp_matrix_s *A, hipStream_t st)
+{
+    if (A->spmv_pos || A->spmv_pos_tried) return;
+    A->spmv_pos_tried = 1;
+    const char *cap_e = getenv("BMSP_SPMV_POSCACHE_MAX");
+    const size_t cap = cap_e ? (size_t)strtoull(cap_e, nullptr, 10) : (size_t)4 << 30;
+    if (getenv("BMSP_SPMV_NO_POSCACHE") || A->block_num == 0) return;
+    const uint64_t base = A->view_values_end ? read_back(A->offsets, st) : 0;  // a row-panel view keeps the parent's absolute offsets
+    const uint64_t count = (uint64_t)A->values_extent() - base;
+    if (count == 0 || count * 2 > cap || count >= (1ull << 31)) return;
+    uint16_t *pos = (uint16_t *)pool_alloc(count * 2 + 64);
+    const char *mem = (const char *)A->spmv_chunks;
+    const uint32_t n_items = (uint32_t)A->spmv_num_chunks;
+    hipLaunchKernelGGL((spmv_vstream_kernel<float, kBuild, kAtomic>), dim3(n_items), dim3(64), 0, st, (const SweepItem *)(mem + 64), n_items, A->keys,
+                       A->bmps, A->offsets, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr,
+                       (uint32_t)A->num_rows, (uint32_t)A->num_cols, 0u, pos, (uint32_t)base, (uint32_t)count);
+    BMSP_CHECK_LAUNCH();
+    A->spmv_pos = pos;
+    A->spmv_pos_base = (int64_t)base;
+    A->spmv_pos_count = (int64_t)count;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // block-row kernels (variants 1 and 2)
 // ---------------------------------------------------------------------------------------------------------
 // one tile row: byte = bits of row r (MSB = column 0), vals points at the first stored value of that row
@@ -664,6 +1000,23 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
         }
         const uint32_t n_items = (uint32_t)A->spmv_num_chunks;
         char *mem = (char *)A->spmv_chunks;
+        if (vstream_eligible(A)) {
+            build_pos_cache(A, st);
+            const bool cached = A->spmv_pos != nullptr;
+            const char *re = getenv("BMSP_SPMV_RED");
+            const int red = re ? atoi(re) : (A->nnz < 2 * A->block_num ? kAtomic : kSorted);
+#define BMSP_VS_LAUNCH(MODE, RED)                                                                                                                   \
+    hipLaunchKernelGGL((spmv_vstream_kernel<T, MODE, RED>), dim3(n_items), dim3(64), 0, st, (const SweepItem *)(mem + 64), n_items, A->keys, A->bmps, \
+                       A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (Ac *)(mem + A->spmv_plan_off_carry),                                \
+                       (uint32_t *)(mem + A->spmv_plan_off_cnt), (uint32_t)A->num_rows, (uint32_t)A->num_cols,                                       \
+                       (uint32_t)((size_t)A->values_extent() * sizeof(T)), A->spmv_pos, (uint32_t)A->spmv_pos_base, (uint32_t)A->spmv_pos_count)
+            if (cached && red == kAtomic) BMSP_VS_LAUNCH(kCached, kAtomic);
+            else if (cached) BMSP_VS_LAUNCH(kCached, kSorted);
+            else if (red == kAtomic) BMSP_VS_LAUNCH(kDecode, kAtomic);
+            else BMSP_VS_LAUNCH(kDecode, kSorted);
+            BMSP_CHECK_LAUNCH();
+            return;
+        }
         const bool nt = getenv("BMSP_SPMV_NT") != nullptr;
         const char *pers = getenv("BMSP_SPMV_PERSIST");
         const char *occ = getenv("BMSP_SPMV_OCC");
@@ -687,6 +1040,8 @@ void prepare_spmv(bmsp_matrix_s *A, hipStream_t st)
     const size_t es = dtype_size(A->dtype);
     if ((size_t)A->values_extent() * es >= (1ull << 32) || (size_t)A->num_cols * es >= (1ull << 32)) return;  // block-row kernel: no plan
     build_plan(A, st);
+    const bool rowgroup = A->block_num > 0 && A->nnz >= 16 * A->block_num && A->spmv_plan_long == 0 && !getenv("BMSP_SPMV_NO_ROWGROUP") && pool_owns(A->values);
+    if (vstream_eligible(A) && !rowgroup) build_pos_cache(A, st);
 }
 
 void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st)

@@ -17,10 +17,10 @@ constexpr uint32_t kItemRows = 16;    // block-rows per item window (u tile = 16
 struct SweepItem {      // 32 bytes, read with scalar loads
     uint32_t row_begin, row_end;  // block-rows [row_begin, row_end)
     uint32_t blk_begin, blk_end;  // tiles [blk_begin, blk_end)
-    uint32_t first_item;          // long rows: index of the row's first item
+    uint32_t first_item;          // long rows: index of the row's first item; short items: offset of the first value past the item
     uint32_t num_items;           // long rows: number of items of the row; 0 = short item
     uint32_t long_idx;            // long rows: arrival counter index
-    uint32_t pad;
+    uint32_t val_begin;           // offset of the item's first stored value (low 32 bits)
 };
 
 // builds (once) and caches the plan in A->spmv_chunks: 64-byte header | items | counters | carry

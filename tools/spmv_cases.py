@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """experiment helper: SpMV kernel time (HIP events, HBM-resident rotation) on the generator structures.
-usage: spmv_cases.py [case-substring] [variant]"""
+usage: spmv_cases.py [case-substring[+case-substring...]] [variant]"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bmsparse-spgemm-spmv_amd"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ import bench
 cases = [("rmat(20,2)", lambda: gen.rmat(20, 2.0)), ("banded(1000000,8)", lambda: gen.banded(1000000, 8)), ("banded(500000,32)", lambda: gen.banded(500000, 32)),
          ("fem_like(47,27pt)", lambda: gen.fem_like(47, "27pt")), ("cage_like(1000000)", lambda: gen.cage_like(1000000)), ("rmat(20,16)", lambda: gen.rmat(20, 16.0))]
 args = [a for a in sys.argv[1:]]
-if args: cases = [c for c in cases if args[0] in c[0]]
+if args: cases = [c for c in cases if any(a in c[0] for a in args[0].split("+"))]
 variant = int(args[1]) if len(args) > 1 else 0
 for name, mk in cases:
     n, _, r, c, v = mk()
