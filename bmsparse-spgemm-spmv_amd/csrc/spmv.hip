@@ -561,8 +561,52 @@ struct VsLds {
     static constexpr uint32_t bytes = srow + (RED == kSorted ? kVsVals : 0);
 };
 
+// what a wave requests for an item before it works on it (kCached): the keys of its first 128 tiles, their end offsets unless the item is
+// a single batch, and entries + values of its first 256 values
+constexpr int kPre = 4;
+template <typename A>
+struct VsPre {
+    uint64_t k0, k1;
+    uint32_t oe0, oe1;
+    uint32_t e[kPre];
+    A a[kPre];
+};
+// values of the item (short items carry their value range; a long-row item holds 256 tiles, its count is not in the plan)
+__device__ __forceinline__ uint32_t vs_item_values(const SweepItem &it) { return it.num_items == 0 ? it.first_item - it.val_begin : 64u * kPre; }
+// the common case: the whole item is one batch, and the item says how many values that is -- no offset is read
+__device__ __forceinline__ bool vs_single(const SweepItem &it)
+{
+    return it.num_items == 0 && it.blk_end - it.blk_begin <= kVsTiles && vs_item_values(it) <= kVsVals;
+}
+template <typename T>
+__device__ __forceinline__ void vs_request(const SweepItem &it, int lane, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ offsets,
+                                           rsrc_t rv, rsrc_t rp, uint32_t pos_base, VsPre<typename Acc<T>::type> &pre)
+{
+    const uint32_t b0 = it.blk_begin + (uint32_t)lane, b1 = b0 + 64u, bend = min(it.blk_begin + kVsTiles, it.blk_end);
+    pre.k0 = pre.k1 = (uint64_t)it.row_begin << 32;
+    pre.oe0 = pre.oe1 = 0;
+    if (b0 < bend) pre.k0 = keys[b0];
+    if (b1 < bend) pre.k1 = keys[b1];
+    if (!vs_single(it)) {
+        if (b0 < bend) pre.oe0 = (uint32_t)offsets[b0 + 1];
+        if (b1 < bend) pre.oe1 = (uint32_t)offsets[b1 + 1];
+    }
+    const uint32_t n_item = vs_item_values(it);
+#pragma unroll
+    for (int u = 0; u < kPre; u++) {
+        const uint32_t idx = 64u * (uint32_t)u + (uint32_t)lane;
+        const bool on = idx < n_item;
+        pre.e[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rp, on ? (it.val_begin - pos_base + idx) * 2u : kOob, 0, 0);
+        pre.a[u] = Buf<T>::ld(rv, on ? (it.val_begin + idx) * (uint32_t)sizeof(T) : kOob);
+    }
+}
+
+// One wave per workgroup (a finished wave frees its slot and its LDS at once), one item per wave.  (A resident grid whose waves walk items
+// id, id + grid, ... with the next item's requests in flight behind the current item's x gathers was built and measured: 33.9 us instead
+// of 28.3 on the webbase-like matrix -- 79 / 114 VGPRs for the two request sets, and the hardware's wave dispatcher balances one-item
+// waves better than a static walk does.)
 template <typename T, int MODE, int RED>
-__global__ __launch_bounds__(64) void spmv_vstream_kernel(const SweepItem *__restrict__ items, uint32_t num_items,
+__global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) void spmv_vstream_kernel(const SweepItem *__restrict__ items, uint32_t num_items,
                                                           const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bmps,
                                                           const uint64_t *__restrict__ offsets, const T *__restrict__ values,
                                                           const T *__restrict__ x, typename Acc<T>::type *__restrict__ y,
@@ -572,7 +616,6 @@ __global__ __launch_bounds__(64) void spmv_vstream_kernel(const SweepItem *__res
 {
     using A = typename Acc<T>::type;
     using L = VsLds<A, MODE, RED>;
-    // one wave per workgroup: a finished wave frees its slot and its LDS at once
     __shared__ __attribute__((aligned(16))) unsigned char lds[L::bytes];
     A *const tile = (A *)(lds + L::tile);
     uint32_t *const tinfo = (uint32_t *)(lds + L::tinfo);
@@ -581,201 +624,203 @@ __global__ __launch_bounds__(64) void spmv_vstream_kernel(const SweepItem *__res
     A *const sorted = (A *)(lds + L::region);
     uint8_t *const srow = lds + L::srow;
     const int lane = lane_id();
-    const uint32_t item_id = blockIdx.x;
-    const SweepItem it = items[item_id];
     const rsrc_t rv = make_rsrc(values, values_bytes), rx = make_rsrc(x, num_cols * (uint32_t)sizeof(T));
     const rsrc_t rp = make_rsrc(pos, pos_count * 2u);
-    tile[lane] = A(0);
-    tile[64 + lane] = A(0);
-    // kCached: entries and values of the item's first 256 values are requested before its tile words are (their place is in the item)
-    constexpr int kPre = 4;
-    uint32_t pre_e[kPre];
-    A pre_a[kPre];
-    if (MODE == kCached) {
-        const uint32_t n_item = it.num_items == 0 ? it.first_item - it.val_begin : 64u * kPre;
-#pragma unroll
-        for (int u = 0; u < kPre; u++) {
-            const uint32_t idx = 64u * (uint32_t)u + (uint32_t)lane;
-            const bool on = idx < n_item;
-            pre_e[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rp, on ? (it.val_begin - pos_base + idx) * 2u : kOob, 0, 0);
-            pre_a[u] = Buf<T>::ld(rv, on ? (it.val_begin + idx) * (uint32_t)sizeof(T) : kOob);
-        }
-    }
+    const uint32_t item_id = blockIdx.x;
+    const SweepItem it = items[item_id];
+    VsPre<A> pre;
+    if (MODE == kCached) vs_request<T>(it, lane, keys, offsets, rv, rp, pos_base, pre);
+    {
+        tile[lane] = A(0);
+        tile[64 + lane] = A(0);
+        const uint32_t n_item = vs_item_values(it);
+        const bool single = MODE == kCached && vs_single(it);
 
-    for (uint32_t base = it.blk_begin; base < it.blk_end;) {
-        const bool first = MODE == kCached && base == it.blk_begin;
-        const uint32_t b0 = base + (uint32_t)lane, b1 = base + 64u + (uint32_t)lane;
-        const uint32_t bend = min(base + kVsTiles, it.blk_end);
-        uint64_t bm0 = 0, bm1 = 0, k0 = (uint64_t)it.row_begin << 32, k1 = k0;
-        uint32_t o0 = 0, o1 = 0, e0 = kOob, e1 = kOob;  // start / end of the tile's values, relative to the batch's first value
-        uint32_t v_first;
-        if (MODE == kCached) {
-            if (b0 < bend) { k0 = keys[b0]; e0 = (uint32_t)offsets[b0 + 1]; }
-            if (b1 < bend) { k1 = keys[b1]; e1 = (uint32_t)offsets[b1 + 1]; }
-            v_first = (uint32_t)offsets[base];
-            e0 -= v_first;
-            e1 -= v_first;
-        } else {
-            if (b0 < bend) { bm0 = bmps[b0]; k0 = keys[b0]; o0 = (uint32_t)offsets[b0]; }
-            if (b1 < bend) { bm1 = bmps[b1]; k1 = keys[b1]; o1 = (uint32_t)offsets[b1]; }
-            v_first = __builtin_amdgcn_readfirstlane(o0);
-            o0 -= v_first;
-            o1 -= v_first;
-            e0 = o0 + (uint32_t)__popcll(bm0);
-            e1 = o1 + (uint32_t)__popcll(bm1);
-        }
-        // the batch: tiles whose values end inside the first kVsVals values (a prefix: offsets ascend; >= 8 tiles, a tile holds <= 64)
-        const bool ok0 = b0 < bend && e0 <= kVsVals, ok1 = b1 < bend && e1 <= kVsVals;
-        const uint32_t n0 = (uint32_t)__popcll(__ballot(ok0)), n1 = (uint32_t)__popcll(__ballot(ok1));
-        const uint32_t nb = n0 + n1;
-        const uint32_t nvals = nb <= 64u ? (uint32_t)__builtin_amdgcn_readlane((int)e0, (int)(nb - 1u)) : (uint32_t)__builtin_amdgcn_readlane((int)e1, (int)(nb - 65u));
-        // tile slots: column and row-in-window of every tile of the batch
-        tinfo[lane] = key_col(k0) | ((key_row(k0) - it.row_begin) << 28);
-        tinfo[64 + lane] = key_col(k1) | ((key_row(k1) - it.row_begin) << 28);
-        if (RED == kSorted) {
-            cnt[lane] = 0;
-            cnt[64 + lane] = 0;
-        }
-        if (MODE != kCached) {
-            // entries from the bitmaps: {slot, position} of every stored value, at the value's index inside the batch
-            uint64_t m0 = ok0 ? bm0 : 0, m1 = ok1 ? bm1 : 0;
-            uint32_t i0 = o0, i1 = o1;
-            while (__any((m0 | m1) != 0)) {
-                if (m0) {
-                    const uint32_t p = (uint32_t)__clzll((long long)m0);
-                    m0 &= ~(0x8000000000000000ull >> p);
-                    ent[i0++] = (uint16_t)(((uint32_t)lane << 6) | p);
-                }
-                if (m1) {
-                    const uint32_t p = (uint32_t)__clzll((long long)m1);
-                    m1 &= ~(0x8000000000000000ull >> p);
-                    ent[i1++] = (uint16_t)(((64u + (uint32_t)lane) << 6) | p);
+        for (uint32_t base = it.blk_begin; base < it.blk_end;) {
+            const bool first = MODE == kCached && base == it.blk_begin;
+            const uint32_t b0 = base + (uint32_t)lane, b1 = base + 64u + (uint32_t)lane;
+            const uint32_t bend = min(base + kVsTiles, it.blk_end);
+            uint64_t bm0 = 0, bm1 = 0, k0 = (uint64_t)it.row_begin << 32, k1 = k0;
+            uint32_t o0 = 0, o1 = 0, e0 = kOob, e1 = kOob;  // start / end of the tile's values, relative to the batch's first value
+            uint32_t v_first;
+            if (first) {
+                k0 = pre.k0;
+                k1 = pre.k1;
+                v_first = it.val_begin;
+                if (b0 < bend) e0 = single ? 0u : pre.oe0 - v_first;
+                if (b1 < bend) e1 = single ? 0u : pre.oe1 - v_first;
+            } else if (MODE == kCached) {
+                if (b0 < bend) { k0 = keys[b0]; e0 = (uint32_t)offsets[b0 + 1]; }
+                if (b1 < bend) { k1 = keys[b1]; e1 = (uint32_t)offsets[b1 + 1]; }
+                v_first = (uint32_t)offsets[base];
+                e0 -= v_first;
+                e1 -= v_first;
+            } else {
+                if (b0 < bend) { bm0 = bmps[b0]; k0 = keys[b0]; o0 = (uint32_t)offsets[b0]; }
+                if (b1 < bend) { bm1 = bmps[b1]; k1 = keys[b1]; o1 = (uint32_t)offsets[b1]; }
+                v_first = __builtin_amdgcn_readfirstlane(o0);
+                o0 -= v_first;
+                o1 -= v_first;
+                e0 = o0 + (uint32_t)__popcll(bm0);
+                e1 = o1 + (uint32_t)__popcll(bm1);
+            }
+            // the batch: tiles whose values end inside the first kVsVals values (a prefix: offsets ascend; >= 8 tiles, a tile holds <= 64)
+            const bool ok0 = b0 < bend && e0 <= kVsVals, ok1 = b1 < bend && e1 <= kVsVals;
+            const uint32_t n0 = (uint32_t)__popcll(__ballot(ok0)), n1 = (uint32_t)__popcll(__ballot(ok1));
+            const uint32_t nb = n0 + n1;
+            const uint32_t nvals = single ? n_item
+                                          : (nb <= 64u ? (uint32_t)__builtin_amdgcn_readlane((int)e0, (int)(nb - 1u)) : (uint32_t)__builtin_amdgcn_readlane((int)e1, (int)(nb - 65u)));
+            // tile slots: column and row-in-window of every tile of the batch
+            tinfo[lane] = key_col(k0) | ((key_row(k0) - it.row_begin) << 28);
+            tinfo[64 + lane] = key_col(k1) | ((key_row(k1) - it.row_begin) << 28);
+            if (RED == kSorted) {
+                cnt[lane] = 0;
+                cnt[64 + lane] = 0;
+            }
+            if (MODE != kCached) {
+                // entries from the bitmaps: {slot, position} of every stored value, at the value's index inside the batch
+                uint64_t m0 = ok0 ? bm0 : 0, m1 = ok1 ? bm1 : 0;
+                uint32_t i0 = o0, i1 = o1;
+                while (__any((m0 | m1) != 0)) {
+                    if (m0) {
+                        const uint32_t p = (uint32_t)__clzll((long long)m0);
+                        m0 &= ~(0x8000000000000000ull >> p);
+                        ent[i0++] = (uint16_t)(((uint32_t)lane << 6) | p);
+                    }
+                    if (m1) {
+                        const uint32_t p = (uint32_t)__clzll((long long)m1);
+                        m1 &= ~(0x8000000000000000ull >> p);
+                        ent[i1++] = (uint16_t)(((64u + (uint32_t)lane) << 6) | p);
+                    }
                 }
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (MODE == kBuild) {
-            for (uint32_t idx = (uint32_t)lane; idx < nvals; idx += 64u) pos[v_first - pos_base + idx] = ent[idx];
+            __builtin_amdgcn_wave_barrier();
+            if (MODE == kBuild) {
+                for (uint32_t idx = (uint32_t)lane; idx < nvals; idx += 64u) pos[v_first - pos_base + idx] = ent[idx];
+                __builtin_amdgcn_wave_barrier();
+                base += nb;
+                continue;
+            }
+            const uint32_t pos_first = (v_first - pos_base) * 2u;
+
+            if (RED == kAtomic) {
+                for (uint32_t c0 = 0; c0 < nvals; c0 += 256u) {
+                    A av[4], xv[4];
+                    uint32_t rowl[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t idx = c0 + 64u * (uint32_t)u + (uint32_t)lane;
+                        const bool on = idx < nvals;
+                        uint32_t e;
+                        if (first && c0 == 0) {
+                            e = pre.e[u];
+                            av[u] = pre.a[u];
+                        } else {
+                            e = MODE == kCached ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rp, on ? pos_first + idx * 2u : kOob, 0, 0) : (on ? (uint32_t)ent[idx] : 0u);
+                            av[u] = Buf<T>::ld(rv, on ? (v_first + idx) * (uint32_t)sizeof(T) : kOob);
+                        }
+                        const uint32_t ti = tinfo[e >> 6], p = e & 63u;
+                        rowl[u] = (ti >> 28) * 8u + (p >> 3);
+                        xv[u] = Buf<T>::ld(rx, on ? ((ti & 0x0fffffffu) * 8u + (p & 7u)) * (uint32_t)sizeof(T) : kOob);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (c0 + 64u * (uint32_t)u + (uint32_t)lane < nvals) lds_add(tile + rowl[u], av[u] * xv[u]);
+                }
+            } else {
+                // the value's rank among the values of its row: integer LDS counter
+                A prod[kVsChunks];
+                A xg[kVsChunks];
+                uint32_t rr[kVsChunks];  // row | rank << 8
+#pragma unroll
+                for (int u = 0; u < kVsChunks; u++) {
+                    if (64u * (uint32_t)u < nvals) {
+                        const uint32_t idx = 64u * (uint32_t)u + (uint32_t)lane;
+                        const bool on = idx < nvals;
+                        uint32_t e;
+                        A av;
+                        if (first && u < kPre) {
+                            e = pre.e[u];
+                            av = pre.a[u];
+                        } else {
+                            e = MODE == kCached ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rp, on ? pos_first + idx * 2u : kOob, 0, 0) : (on ? (uint32_t)ent[idx] : 0u);
+                            av = Buf<T>::ld(rv, on ? (v_first + idx) * (uint32_t)sizeof(T) : kOob);
+                        }
+                        const uint32_t ti = tinfo[e >> 6], p = e & 63u;
+                        const uint32_t rowl = (ti >> 28) * 8u + (p >> 3);
+                        xg[u] = Buf<T>::ld(rx, on ? ((ti & 0x0fffffffu) * 8u + (p & 7u)) * (uint32_t)sizeof(T) : kOob);
+                        uint32_t rank = 0;
+                        if (on) rank = __hip_atomic_fetch_add(&cnt[rowl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        rr[u] = rowl | (rank << 8);
+                        prod[u] = av;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // row counters -> row starts (exclusive sums; lane l owns rows 2l and 2l+1)
+                {
+                    const uint32_t c0 = cnt[2 * lane], c1 = cnt[2 * lane + 1];
+                    const uint32_t ex = wave_inclusive_sum_dpp(c0 + c1) - (c0 + c1);
+                    cnt[2 * lane] = ex;
+                    cnt[2 * lane + 1] = ex + c0;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // products into row order (the entries of kDecode live in the same bytes: all of them were read above)
+#pragma unroll
+                for (int u = 0; u < kVsChunks; u++) {
+                    if (64u * (uint32_t)u < nvals) {
+                        if (64u * (uint32_t)u + (uint32_t)lane < nvals) {
+                            const uint32_t rowl = rr[u] & 0xffu, at = cnt[rowl] + (rr[u] >> 8);
+                            sorted[at] = prod[u] * xg[u];
+                            srow[at] = (uint8_t)rowl;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // run sums; the last lane of every run adds its sum to the u tile (one lane per row and chunk: no atomic)
+#pragma unroll
+                for (int u = 0; u < kVsChunks; u++) {
+                    if (64u * (uint32_t)u < nvals) {
+                        const uint32_t idx = 64u * (uint32_t)u + (uint32_t)lane;
+                        const bool on = idx < nvals;
+                        const A sv = on ? sorted[idx] : A(0);
+                        const uint32_t row = on ? (uint32_t)srow[idx] : 0xfeu;
+                        const uint32_t nxt = (lane < 63 && idx + 1u < nvals) ? (uint32_t)srow[idx + 1u] : 0xffu;
+                        const A run = wave_run_sum(sv, row);
+                        if (on && nxt != row) tile[row] += run;
+                    }
+                }
+            }
             __builtin_amdgcn_wave_barrier();
             base += nb;
-            continue;
         }
-        const uint32_t pos_first = (v_first - pos_base) * 2u;
 
-        if (RED == kAtomic) {
-            for (uint32_t c0 = 0; c0 < nvals; c0 += 256u) {
-                A av[4], xv[4];
-                uint32_t rowl[4];
+        if (MODE != kBuild) {
+            if (it.num_items == 0) {
+                // short item: the wave owns u[row_begin*8, row_end*8)
+                const uint32_t n_out = (it.row_end - it.row_begin) * 8u, out0 = it.row_begin * 8u;
+                for (uint32_t e = lane; e < n_out; e += 64)
+                    if (out0 + e < num_rows) y[out0 + e] = tile[e];
+            } else {
+                // long row: park the partial sums, the last arriver folds them (same protocol as spmv_sweep_kernel)
+                if (lane < 8) __hip_atomic_store(&carry[(size_t)item_id * 8 + lane], tile[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t ticket = 0;
+                if (lane == 0) ticket = __hip_atomic_fetch_add(&counters[it.long_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ticket = __builtin_amdgcn_readfirstlane(ticket);
+                if (ticket == it.num_items - 1) {
+                    const int r = lane & 7, g = lane >> 3;
+                    A sum = 0;
+                    for (uint32_t c = g; c < it.num_items; c += 8)
+                        sum += __hip_atomic_load(&carry[(size_t)(it.first_item + c) * 8 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t idx = c0 + 64u * (uint32_t)u + (uint32_t)lane;
-                    const bool on = idx < nvals;
-                    uint32_t e;
-                    if (first && c0 == 0) {
-                        e = pre_e[u];
-                        av[u] = pre_a[u];
-                    } else {
-                        e = MODE == kCached ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rp, on ? pos_first + idx * 2u : kOob, 0, 0) : (on ? (uint32_t)ent[idx] : 0u);
-                        av[u] = Buf<T>::ld(rv, on ? (v_first + idx) * (uint32_t)sizeof(T) : kOob);
-                    }
-                    const uint32_t ti = tinfo[e >> 6], p = e & 63u;
-                    rowl[u] = (ti >> 28) * 8u + (p >> 3);
-                    xv[u] = Buf<T>::ld(rx, on ? ((ti & 0x0fffffffu) * 8u + (p & 7u)) * (uint32_t)sizeof(T) : kOob);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (c0 + 64u * (uint32_t)u + (uint32_t)lane < nvals) lds_add(tile + rowl[u], av[u] * xv[u]);
-            }
-        } else {
-            // the value's rank among the values of its row: integer LDS counter
-            A prod[kVsChunks];
-            uint32_t rr[kVsChunks];  // row | rank << 8
-#pragma unroll
-            for (int u = 0; u < kVsChunks; u++) {
-                if (64u * (uint32_t)u < nvals) {
-                    const uint32_t idx = 64u * (uint32_t)u + (uint32_t)lane;
-                    const bool on = idx < nvals;
-                    uint32_t e;
-                    A av;
-                    if (first && u < kPre) {
-                        e = pre_e[u];
-                        av = pre_a[u];
-                    } else {
-                        e = MODE == kCached ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rp, on ? pos_first + idx * 2u : kOob, 0, 0) : (on ? (uint32_t)ent[idx] : 0u);
-                        av = Buf<T>::ld(rv, on ? (v_first + idx) * (uint32_t)sizeof(T) : kOob);
-                    }
-                    const uint32_t ti = tinfo[e >> 6], p = e & 63u;
-                    const uint32_t rowl = (ti >> 28) * 8u + (p >> 3);
-                    const A xv = Buf<T>::ld(rx, on ? ((ti & 0x0fffffffu) * 8u + (p & 7u)) * (uint32_t)sizeof(T) : kOob);
-                    uint32_t rank = 0;
-                    if (on) rank = __hip_atomic_fetch_add(&cnt[rowl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    rr[u] = rowl | (rank << 8);
-                    prod[u] = av * xv;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // row counters -> row starts (exclusive sums; lane l owns rows 2l and 2l+1)
-            {
-                const uint32_t c0 = cnt[2 * lane], c1 = cnt[2 * lane + 1];
-                const uint32_t ex = wave_inclusive_sum_dpp(c0 + c1) - (c0 + c1);
-                cnt[2 * lane] = ex;
-                cnt[2 * lane + 1] = ex + c0;
-            }
-            __builtin_amdgcn_wave_barrier();
-            // products into row order (the entries of kDecode live in the same bytes: all of them were read above)
-#pragma unroll
-            for (int u = 0; u < kVsChunks; u++) {
-                if (64u * (uint32_t)u < nvals) {
-                    if (64u * (uint32_t)u + (uint32_t)lane < nvals) {
-                        const uint32_t rowl = rr[u] & 0xffu, at = cnt[rowl] + (rr[u] >> 8);
-                        sorted[at] = prod[u];
-                        srow[at] = (uint8_t)rowl;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // run sums; the last lane of every run adds its sum to the u tile (one lane per row and chunk: no atomic)
-#pragma unroll
-            for (int u = 0; u < kVsChunks; u++) {
-                if (64u * (uint32_t)u < nvals) {
-                    const uint32_t idx = 64u * (uint32_t)u + (uint32_t)lane;
-                    const bool on = idx < nvals;
-                    const A sv = on ? sorted[idx] : A(0);
-                    const uint32_t row = on ? (uint32_t)srow[idx] : 0xfeu;
-                    const uint32_t nxt = (lane < 63 && idx + 1u < nvals) ? (uint32_t)srow[idx + 1u] : 0xffu;
-                    const A run = wave_run_sum(sv, row);
-                    if (on && nxt != row) tile[row] += run;
+                    for (int d = 8; d < 64; d <<= 1) sum += __shfl_xor(sum, d, kWave);
+                    const uint32_t row = it.row_begin * 8u + (uint32_t)r;
+                    if (g == 0 && row < num_rows) y[row] = sum;
+                    if (lane == 0) __hip_atomic_store(&counters[it.long_idx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        base += nb;
     }
-    if (MODE == kBuild) return;
-
-    if (it.num_items == 0) {
-        // short item: the wave owns u[row_begin*8, row_end*8)
-        const uint32_t n_out = (it.row_end - it.row_begin) * 8u, out0 = it.row_begin * 8u;
-        for (uint32_t e = lane; e < n_out; e += 64)
-            if (out0 + e < num_rows) y[out0 + e] = tile[e];
-        return;
-    }
-    // long row: park the partial sums, the last arriver folds them (same protocol as spmv_sweep_kernel)
-    if (lane < 8) __hip_atomic_store(&carry[(size_t)item_id * 8 + lane], tile[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t ticket = 0;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(&counters[it.long_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != it.num_items - 1) return;
-    const int r = lane & 7, g = lane >> 3;
-    A sum = 0;
-    for (uint32_t c = g; c < it.num_items; c += 8)
-        sum += __hip_atomic_load(&carry[(size_t)(it.first_item + c) * 8 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int d = 8; d < 64; d <<= 1) sum += __shfl_xor(sum, d, kWave);
-    const uint32_t row = it.row_begin * 8u + (uint32_t)r;
-    if (g == 0 && row < num_rows) y[row] = sum;
-    if (lane == 0) __hip_atomic_store(&counters[it.long_idx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // the position cache: kBuild pass over the plan's items, once per matrix
@@ -1005,10 +1050,10 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
             const bool cached = A->spmv_pos != nullptr;
             const char *re = getenv("BMSP_SPMV_RED");
             const int red = re ? atoi(re) : (A->nnz < 2 * A->block_num ? kAtomic : kSorted);
-#define BMSP_VS_LAUNCH(MODE, RED)                                                                                                                   \
+#define BMSP_VS_LAUNCH(MODE, RED)                                                                                                                \
     hipLaunchKernelGGL((spmv_vstream_kernel<T, MODE, RED>), dim3(n_items), dim3(64), 0, st, (const SweepItem *)(mem + 64), n_items, A->keys, A->bmps, \
-                       A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (Ac *)(mem + A->spmv_plan_off_carry),                                \
-                       (uint32_t *)(mem + A->spmv_plan_off_cnt), (uint32_t)A->num_rows, (uint32_t)A->num_cols,                                       \
+                       A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (Ac *)(mem + A->spmv_plan_off_carry),                             \
+                       (uint32_t *)(mem + A->spmv_plan_off_cnt), (uint32_t)A->num_rows, (uint32_t)A->num_cols,                                    \
                        (uint32_t)((size_t)A->values_extent() * sizeof(T)), A->spmv_pos, (uint32_t)A->spmv_pos_base, (uint32_t)A->spmv_pos_count)
             if (cached && red == kAtomic) BMSP_VS_LAUNCH(kCached, kAtomic);
             else if (cached) BMSP_VS_LAUNCH(kCached, kSorted);
