@@ -258,7 +258,10 @@ def main():
     traffic = None
     if "coo" in wl and not args.spmv_matrix and args.scale == 20 and args.edge_factor == 2.0:
         traffic = profile_json("r*_spmv_webbase_like*_traffic.json", "traffic_bytes_per_launch")
-    roofline = {"bound": "hbm", "kernel": "spmv_sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # the kernel the default variant launches here: value-stream (sparse tiles), FULL sweep / row-group (dense tiles); see spmv.hip
+    vpt = info["nnz"] / max(1, info["block_num"])
+    kern_name = ("spmv_vstream_kernel<float, kCached, %s>" % ("kAtomic" if vpt < 2 else "kSorted")) if vpt < 16 else "spmv_rowgroup_kernel / spmv_sweep_kernel<FULL>"
+    roofline = {"bound": "hbm", "kernel": kern_name if variant == 0 else "spmv_blockrow_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(kern_ms, 5)}
 
@@ -268,7 +271,7 @@ def main():
            "data": "synthetic" if "coo" in wl else "suitesparse",
            "config": {"workload": "bmSparse SpMV fp32, " + wl["name"], "rows": info["num_rows"], "nnz": info["nnz"],
                       "blocks": info["block_num"], "values_per_tile": round(info["nnz"] / max(1, info["block_num"]), 3),
-                      "x": "ones", "variant": ["sweep (default)", "batched", "row-group"][variant],
+                      "x": "ones", "variant": ["default (value-stream sweep over the cached plan)", "batched", "row-group"][variant],
                       "hbm_resident_copies_rotated": copies, "effective_bytes_per_spmv": eff_bytes},
            "warm_ms_per_step": round(warm_ms, 5), "warm_effective_GBs": round(eff_bytes / (warm_ms * 1e-3) / 1e9, 1),
            "roofline": roofline}

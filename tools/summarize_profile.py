@@ -5,14 +5,15 @@ import csv, glob, collections, os, shutil, sys
 src, tag, kern = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "spmv_sweep")
 cmd = sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --skip-cpu --skip-spgemm --steps 100 --warmup 10"
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 lines = ["# rocprofv3 summary `%s` (source: %s)" % (tag, src), "",
          "command: `rocprofv3 --kernel-trace --stats --output-format csv -- %s` and, in separate runs, "
          "`rocprofv3 --pmc <counters>` with the same command." % cmd, ""]
 if stats:
     shutil.copy(stats[0], "profiles/%s_kernel_stats.csv" % tag)
     lines += ["## kernel-trace --stats (top kernels)", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
-    for i, row in enumerate(csv.DictReader(open(stats[0]))):
+    rows = sorted(csv.DictReader(open(stats[0])), key=lambda r: -float(r["TotalDurationNs"]))
+    for i, row in enumerate(rows):
         if i >= 14: break
         nm = row["Name"]
         if nm.startswith("_Z"):  # left mangled by the tool: keep the readable middle
@@ -24,7 +25,7 @@ if stats:
 lines += ["", "## PMC counters of `%s` (average per dispatch)" % kern, "", "| pass | counter | value |", "|---|---|---|"]
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d): continue
-    f = glob.glob(os.path.join(d, "*/*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(d, "*/*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not f: continue
     agg = collections.defaultdict(lambda: [0, 0.0])
     for row in csv.DictReader(open(f[0])):
@@ -40,7 +41,7 @@ lines += ["", "Notes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE c
 import json
 tot = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-    f = glob.glob(os.path.join(d, "*/*_counter_collection.csv")) if os.path.isdir(d) else []
+    f = sorted(glob.glob(os.path.join(d, "*/*_counter_collection.csv")), key=os.path.getmtime, reverse=True) if os.path.isdir(d) else []
     if not f: continue
     agg = collections.defaultdict(lambda: [0, 0.0])
     for row in csv.DictReader(open(f[0])):
