@@ -277,6 +277,67 @@ def test_spmv_rowgroup_kernel(bmsp, dtype, case):
     np.testing.assert_array_equal(got[0].view(np.uint8), got[1].view(np.uint8))
 
 
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("mode", ["cached+auto", "cached+atomic", "cached+sorted", "decode+atomic", "decode+sorted"])
+@pytest.mark.parametrize("case", ["rmat_hubs", "fem", "mid_density", "long_row", "empty_rows_ragged", "panel_view"])
+def test_spmv_value_stream_modes(bmsp, monkeypatch, dtype, mode, case):
+    """the value-stream kernel (lane per stored value; default for matrices of sparse tiles) in every entry source x reduction:
+    entries from the per-matrix position cache or decoded from the bitmaps in LDS; LDS float atomics or counting sort + run sums.
+    Cases: hub rows cut into 256-tile items with carry slots, items of several batches (> 128 tiles / > 512 values per batch), a
+    block-row longer than one item, empty block-rows over a NaN-poisoned y with ragged last row / column, and a row-panel view
+    (absolute offsets into the parent's values: the cache is indexed relative to the panel's first value).  Against scipy float64 on
+    the rounded inputs; the sorted reduction must be bit-reproducible across sweeps."""
+    import scipy.sparse as sp
+    from pybmsp import gen
+    src, red = mode.split("+")
+    if src == "decode":
+        monkeypatch.setenv("BMSP_SPMV_NO_POSCACHE", "1")
+    if red != "auto":
+        monkeypatch.setenv("BMSP_SPMV_RED", "0" if red == "atomic" else "1")
+    lo = hi = None
+    if case == "rmat_hubs":
+        nr, _, r, c, v = gen.rmat(13, 6.0)
+        nc = nr
+    elif case == "fem":
+        nr, _, r, c, v = gen.fem_like(14, "27pt", window=8)
+        nc = nr
+    elif case == "mid_density":
+        nr, nc = 1501, 2003
+        _, _, r, c, v = gen.random_coo(nr, nc, 260000, seed=21)  # ~6 values per tile: batches hit the 512-value cut
+    elif case == "long_row":
+        nr, nc = 24, 60011
+        _, _, r, c, v = gen.random_coo(nr, nc, 90000, seed=22)   # ~7500 tiles per block-row: long-row items + fold
+    elif case == "empty_rows_ragged":
+        nr, nc = 4003, 517
+        _, _, r, c, v = gen.random_coo(nr, nc, 9000, seed=23)
+        keep = (r // 8) % 3 != 1
+        r, c, v = r[keep], c[keep], v[keep]
+    else:
+        nr, _, r, c, v = gen.rmat(12, 4.0)
+        nc = nr
+        lo, hi = 100, 390  # block-rows of the panel
+    np_in = bmsp.NP_DTYPE[dtype]
+    vq = np.asarray(v, np.float64).astype(np_in)
+    A = bmsp.BmSpMatrix.from_coo(nr, nc, r, c, v, dtype=dtype)
+    info = A.info()
+    assert info["nnz"] < 16 * info["block_num"]  # sparse tiles: the default variant takes the value-stream kernel
+    x = gen.spmv_x(nc, "cusp").astype(np_in)
+    S = sp.coo_matrix((vq.astype(np.float64), (r, c)), shape=(nr, nc)).tocsr()
+    M, sel = A, slice(0, nr)
+    if lo is not None:
+        M, sel = A.row_panel(lo, hi), slice(lo * 8, hi * 8)  # a view keeps the parent's row numbering; only its rows are written
+    want = (S @ x.astype(np.float64))[sel]
+    mag = (abs(S) @ np.abs(x.astype(np.float64)))[sel]
+    tol = {0: 1e-5, 1: 1e-5, 2: 1e-13}[dtype]
+    dx = bmsp.DeviceArray.from_host(x)
+    for rep in range(2):
+        y = bmsp.DeviceArray(nr, bmsp.OUT_DTYPE[dtype])
+        assert bmsp.lib().bmsp_memset(y.ptr, 0xFF, nr * y.dtype.itemsize) == 0
+        bmsp.check(bmsp.lib().bmsp_spmv(M.h, dx.ptr, y.ptr, 0, None))
+        got = y.to_host()[sel].astype(np.float64)
+        assert np.all(np.abs(got - want) <= tol * mag + 1e-30)
+
+
 def test_spmv_bench_size_properties(bmsp):
     """the SpMV bench workload at its full size (R-MAT 2^20 x 2 + I, the webbase-1M stand-in): A*1 equals the host row sums, two
     sweeps are bit-identical (arrival counters reset, fixed fold order of hub rows), the block-row variants agree within tolerance."""
