@@ -336,7 +336,7 @@ void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const
 // LDS traffic of the generic (u64 key, u16 position) network above).  Segments up to 1024 tasks stay inside one wave
 // (no s_barrier between the network's steps); longer ones take a 512-thread workgroup.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kTaskWaveMax = 1024, kTaskWaveIdxBits = 10, kTaskBlockIdxBits = 12;
+constexpr uint32_t kTaskWaveMax = 2048, kTaskBlockIdxBits = 12;
 
 template <typename W, int THREADS, bool BLOCK_SYNC, uint32_t IDX_BITS>
 __device__ __forceinline__ void sort_task_segment(W *a, uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, uint64_t lo, uint32_t len, uint32_t p_min,
@@ -356,18 +356,118 @@ __device__ __forceinline__ void sort_task_segment(W *a, uint64_t *__restrict__ k
     }
 }
 
+// ---- one wave per segment, the words in REGISTERS ---------------------------------------------------------------------------------
+// Blocked layout: lane l holds words l*E .. l*E + E-1 of the 64*E-word network.  A compare-exchange at distance j < E is two VALU
+// instructions on two registers of one lane; at distance j >= E the partner is the same register of lane l ^ (j / E): a DPP operand for
+// lane distances 1, 2 and 8 (14 of the 21 cross-lane steps of any size), ds_swizzle for 4 and 16, one bpermute for 32.  The LDS network
+// above reads and writes LDS twice per compare-exchange and computes two indices for it; here 45 of the 66 steps of a 2048-word sort never
+// leave the registers.  Descending runs are sorted ascending on complemented words (one xor per word and phase) so that every
+// compare-exchange is a plain (min, max).
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v)
+{
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
+    else if constexpr (M == 4 || M == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1f);  // bit mode: xor M
+    else return (uint32_t)__shfl_xor((int)v, 32, kWave);
+}
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) { return lane_xor_u32<M>(v); }
+template <int M>
+__device__ __forceinline__ uint64_t lane_xor(uint64_t v)
+{
+    return ((uint64_t)lane_xor_u32<M>((uint32_t)(v >> 32)) << 32) | lane_xor_u32<M>((uint32_t)v);
+}
+
+template <typename W, int E, int K, int J>
+struct BitonicStep {
+    static __device__ __forceinline__ void run(W (&x)[E], int lane)
+    {
+        if constexpr (J >= E) {
+            constexpr int M = J / E;
+            const bool lower = (lane & M) == 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const W y = lane_xor<M>(x[e]);
+                const W mn = x[e] < y ? x[e] : y, mx = x[e] < y ? y : x[e];
+                x[e] = lower ? mn : mx;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if ((e & J) == 0) {
+                    const bool down = K < E && (e & K) != 0;  // inside a lane the direction is a property of the register
+                    const W a = x[e], b = x[e | J];
+                    const W mn = a < b ? a : b, mx = a < b ? b : a;
+                    x[e] = down ? mx : mn;
+                    x[e | J] = down ? mn : mx;
+                }
+            }
+        }
+        if constexpr (J > 1) BitonicStep<W, E, K, J / 2>::run(x, lane);
+    }
+};
+template <typename W, int E, int K>
+struct BitonicPhase {
+    static __device__ __forceinline__ void run(W (&x)[E], int lane)
+    {
+        // K >= E: the run's direction belongs to the lane (bit K / E of it; the last phase is ascending everywhere)
+        const bool flip = K >= E && K < 64 * E && (lane & (K / E)) != 0;
+        if constexpr (K >= E && K < 64 * E) {
+#pragma unroll
+            for (int e = 0; e < E; e++) x[e] = flip ? (W)~x[e] : x[e];
+        }
+        BitonicStep<W, E, K, K / 2>::run(x, lane);
+        if constexpr (K >= E && K < 64 * E) {
+#pragma unroll
+            for (int e = 0; e < E; e++) x[e] = flip ? (W)~x[e] : x[e];
+        }
+        if constexpr (K < 64 * E) BitonicPhase<W, E, K * 2>::run(x, lane);
+    }
+};
+
+template <typename W, int E, uint32_t IDX_BITS>
+__device__ __forceinline__ void sort_task_segment_regs(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, uint64_t lo, uint32_t len, uint64_t col_mask,
+                                                       int lane)
+{
+    W x[E];
+    const uint64_t row_part = keys[lo] & ~col_mask;  // constant inside a segment
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
+        x[e] = i < len ? (W)(((keys[lo + i] & col_mask) << IDX_BITS) | i) : (W)~(W)0;
+    }
+    BitonicPhase<W, E, 2>::run(x, lane);
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
+        if (i < len) {
+            keys[lo + i] = row_part | (uint64_t)(x[e] >> IDX_BITS);
+            perm[lo + i] = (uint32_t)(lo + (uint32_t)(x[e] & (W)((1u << IDX_BITS) - 1u)));
+        }
+    }
+}
+
+// (two launches over the same list -- segments of <= 512 words in a kernel of their own at full occupancy -- were measured: the second
+// launch costs more than the occupancy returns, cage-like T_5 195 -> 220 us)
 template <typename W>
 __global__ __launch_bounds__(kThreads) void segsort_tasks_wave_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, const int *__restrict__ segs,
                                                                       uint32_t nseg, uint64_t n, const uint32_t *__restrict__ list, uint32_t count,
                                                                       uint64_t col_mask)
 {
-    __shared__ W s_a[4][kTaskWaveMax];
-    const int w = wave_id();
-    const uint32_t li = blockIdx.x * 4 + w;
+    const uint32_t li = blockIdx.x * 4 + (uint32_t)wave_id();
     if (li >= count) return;
     const uint32_t s = list[li];
     const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
-    sort_task_segment<W, 64, false, kTaskWaveIdxBits>(s_a[w], keys, perm, lo, (uint32_t)(hi - lo), 2u, col_mask, (uint32_t)lane_id());
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hi - lo));
+    const int lane = lane_id();
+    if (len <= 128) sort_task_segment_regs<W, 2, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else if (len <= 256) sort_task_segment_regs<W, 4, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else if (len <= 512) sort_task_segment_regs<W, 8, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else if (len <= 1024) sort_task_segment_regs<W, 16, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else if (sizeof(W) == 8 || len <= 2048) sort_task_segment_regs<W, 32, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else if constexpr (sizeof(W) == 4) sort_task_segment_regs<W, 64, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);  // 64 words per lane
 }
 
 template <typename W>
@@ -384,7 +484,7 @@ template <typename W>
 bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *segs, uint32_t nseg, int jbits, hipStream_t st)
 {
     if (nseg >= (1u << 21)) return false;
-    SegClassify cls{segs, nseg, n, kTaskWaveMax};
+    SegClassify cls{segs, nseg, n, sizeof(W) == 4 ? 2 * kTaskWaveMax : kTaskWaveMax};  // 32-bit words: a wave holds a 4096-word segment in registers
     DevBuf<uint32_t> wave_list(nseg), block_list(nseg);
     HostScalar<uint64_t> tot;
     device_exclusive_scan<uint64_t>(cls, SegLists{cls, wave_list.p, block_list.p, tot.dev(), perm}, (uint64_t)nseg + 1, st);
@@ -412,6 +512,8 @@ bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals,
     HostScalar<uint32_t> cnt;
     device_exclusive_scan<uint32_t>(RunHead{keys.cur, n, jbits}, EmitRunStarts{keys.cur, n, jbits, segs.p, cnt.dev()}, n + 1, st);
     const uint32_t nseg = cnt.wait(st);
+    // (moving the payload inside the sort kernels -- no permutation array, no gather pass -- was measured: T_5 605 -> 983 us on the
+    // FEM-like product; E scattered 8-byte gathers per lane at 3 waves per SIMD are slower than one fully parallel gather pass)
     DevBuf<uint32_t> perm(n);
     const bool narrow = jbits + (int)kTaskBlockIdxBits <= 32;
     const bool ok = narrow ? segsort_tasks_lds<uint32_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st)
