@@ -332,6 +332,117 @@ __global__ __launch_bounds__(kThreads, 4) void block_mac_mfma32_kernel(Mac32Args
     }
 }
 
+// ---- the direct kernel: operands straight from the dense copies into the MFMA lanes, no LDS -------------------------------------------
+// For products with many tasks per C tile (FEM-like: 14) the staging above is overhead: the MFMA lane (K slot ks = l >> 4, tile of the
+// pair (l >> 3) & 1, line r = l & 7) wants exactly ONE 16-byte line of A's dense copy and ONE of B's -- the lines 8 lanes of a
+// task-parallel fetch would park in LDS.  Here every lane loads its own two lines (8 lanes = one 128-byte tile) of task 4 * step + ks of
+// its C tile and feeds them to the MFMA; a pair of consecutive C tiles takes max(n0, n1) / 4 steps.  The pipeline is three deep over the
+// flattened (pair, step) sequence: task word of step g + 2, lines of step g + 1, MFMA of step g.  Finished pairs are stored from the
+// accumulator lanes: lane (tile dt = l >> 5, rows 4 * ((l >> 4) & 1) + i, column l & 7) holds four elements of one column; each goes to
+// rank(C bitmap, position) of its tile.
+//   Measured (T_7, us): FEM-like 890 -> 580, full-tile banded 73 -> 55; R-MAT 2^16 (4.5 tasks per C tile, skewed) 2590 -> 3110 and
+//   cage-like (1.2) 428 -> 652: pairs of tiles with unequal, small task counts leave most operand slots empty, so the launcher takes this
+//   kernel at >= 4.6 tasks per C tile only.  Running the two diagonal blocks as independent tile streams (no max(n0, n1)) was slower on
+//   every case (FEM-like 666, banded 69): the streams' tiles are half a quota apart and stop sharing A / B lines in the L1.
+typedef uint32_t u32x2v_t __attribute__((ext_vector_type(2)));
+struct DirectPos {
+    uint32_t c;       // first tile of the pair
+    uint32_t s, steps;
+    uint32_t tb, n;   // per lane: first task and task count of the lane's tile of the pair
+};
+
+__global__ __launch_bounds__(kThreads) void block_mac_direct_kernel(Mac32Args g)
+{
+    const int w = wave_id(), lane = lane_id();
+    const int r = lane & 7, sel = (lane >> 3) & 1, ks = lane >> 4;
+    const rsrc_t rda = make_rsrc(g.a_dense, g.a_dense_bytes), rdb = make_rsrc(g.b_dense, g.b_dense_bytes);
+    const rsrc_t rtk = make_rsrc(g.tasks, g.n_tasks * 8u);
+    uint32_t wg;
+    {
+        const uint32_t G = gridDim.x, q = G / 8, rm = G % 8, x = blockIdx.x % 8;
+        wg = (x < rm ? x * (q + 1) : rm * (q + 1) + (x - rm) * q) + blockIdx.x / 8;
+    }
+    const uint32_t wv = wg * 4 + w;
+    uint32_t rs = g.c_size;
+    if (lane < 2) {
+        const uint64_t t = (uint64_t)(wv + lane) * g.quota;
+        if (t < g.n_tasks) {
+            const uint32_t c = g.c_of_wave[t >> 6];
+            rs = g.task_begin[c] == (uint32_t)t ? c : c + 1;
+        }
+    }
+    const uint32_t c0 = rl(rs, 0), ce = rl(rs, 1);
+    if (c0 >= ce) return;
+
+    // a pair's words: task_begin[c .. c + 2] (wave-uniform scalar loads), the lane's tile = c + sel
+    auto enter = [&](uint32_t c) {
+        DirectPos p;
+        p.c = c;
+        p.s = 0;
+        const uint32_t t0 = g.task_begin[c], t1 = g.task_begin[c + 1], t2 = c + 1 < ce ? g.task_begin[c + 2] : t1;
+        const uint32_t n0 = t1 - t0, n1 = t2 - t1;
+        p.steps = (max(n0, n1) + 3u) / 4u;
+        p.tb = sel ? t1 : t0;
+        p.n = sel ? n1 : n0;
+        return p;
+    };
+    auto advance = [&](const DirectPos &p) {
+        DirectPos q = p;
+        q.s = p.s + 1;
+        if (q.s >= p.steps) {
+            if (p.c + 2 < ce) q = enter(p.c + 2);
+            else { q.c = ce; q.s = 0; q.steps = 0; q.tb = 0; q.n = 0; }  // past the end: its loads are masked off
+        }
+        return q;
+    };
+    auto load_task = [&](const DirectPos &p) -> uint64_t {
+        const uint32_t ti = 4u * p.s + (uint32_t)ks;
+        const u32x2v_t t = __builtin_amdgcn_raw_buffer_load_b64(rtk, (p.c < ce && ti < p.n) ? (p.tb + ti) * 8u : kOob, 0, 0);
+        return ((uint64_t)t[1] << 32) | t[0];
+    };
+    auto lines = [&](const DirectPos &p, uint64_t tk, half8_t &fa, half8_t &fb) {
+        const bool on = p.c < ce && 4u * p.s + (uint32_t)ks < p.n;
+        fa = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rda, on ? ((uint32_t)(tk >> 32) << 7) + (uint32_t)(r * 16) : kOob, 0, 0));
+        fb = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rdb, on ? ((uint32_t)tk << 7) + (uint32_t)(r * 16) : kOob, 0, 0));
+    };
+
+    DirectPos pa = enter(c0);
+    uint64_t tka = load_task(pa);
+    DirectPos pb = advance(pa);
+    uint64_t tkb = load_task(pb);
+    half8_t fa, fb;
+    lines(pa, tka, fa, fb);
+    float4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const int dt = lane >> 5;
+    const bool d_lane = dt == sel;
+
+    while (pa.c < ce) {
+        // lines of the next step, task word of the one after
+        half8_t na, nb;
+        lines(pb, tkb, na, nb);
+        const DirectPos pc = advance(pb);
+        const uint64_t tkc = load_task(pc);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
+        if (pa.s + 1 == pa.steps) {
+            // the pair is complete: compacted store by the C bitmap of the lane's tile
+            const uint32_t ct = pa.c + (uint32_t)dt;
+            if (d_lane && ct < ce) {
+                const uint64_t cb = g.c_bmps[ct], co = g.c_offs[ct];
+                const uint32_t row0 = 4u * (uint32_t)((lane >> 4) & 1);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t p = (row0 + (uint32_t)i) * 8u + (uint32_t)r;
+                    if ((cb >> (63u - p)) & 1ull) g.c_vals[co + (uint64_t)__popcll(cb >> 1 >> (63u - p))] = acc[i];
+                }
+            }
+            acc = float4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        pa = pb; pb = pc;
+        tkb = tkc;
+        fa = na; fb = nb;
+    }
+}
+
 // lane-layout self test of v_mfma_f32_16x16x32_f16: A[i][k] = i + 16 k (exact in fp16 up to 2048), B[k][j] = asymmetric small
 // integers; the host checks D = A * B element by element (bmsp_selftest_mfma_layout)
 __global__ void mfma32_selftest_kernel(float *d_out)
@@ -413,7 +524,11 @@ void launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *
     }
     const char *venv = getenv("BMSP_MAC_VARIANT");  // timing experiments: 4 = no store phase, 8 = no MFMA loop, 16 = no staging (wrong results)
     const int v = venv ? atoi(venv) : 0;
-    if (b_dense) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, true, 0>), dim3(grid), dim3(kThreads), 0, st, g);
+    // >= 4.6 tasks per C tile: the direct kernel (no LDS); sparser task lists keep the staged one (BMSP_MAC_DIRECT = 0 / 1 forces)
+    const char *de = getenv("BMSP_MAC_DIRECT");
+    const bool direct = b_dense && (de ? de[0] == '1' : 10 * n_tasks >= 46 * (uint64_t)cs);
+    if (direct) hipLaunchKernelGGL(block_mac_direct_kernel, dim3(grid), dim3(kThreads), 0, st, g);
+    else if (b_dense) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, true, 0>), dim3(grid), dim3(kThreads), 0, st, g);
     else if (v == 4) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 4>), dim3(grid), dim3(kThreads), 0, st, g);
     else if (v == 8) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 8>), dim3(grid), dim3(kThreads), 0, st, g);
     else if (v == 16) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 16>), dim3(grid), dim3(kThreads), 0, st, g);

@@ -452,15 +452,22 @@ def test_mfma_16x16x32_lane_layout(bmsp):
     assert bad.value == 0
 
 
-@pytest.mark.parametrize("b_dense", ["0", "1"])
+@pytest.mark.parametrize("b_dense", ["0", "1", "direct"])
 @pytest.mark.parametrize("quota", ["64", ""])
 @pytest.mark.parametrize("case", ["rmat", "banded_full", "hub_c_blocks", "rect_ragged", "ragusa"])
 def test_mfma32_block_mac_paths(oracle, bmsp, monkeypatch, case, b_dense, quota):
-    """the K = 32 block-MAC (tc_version 4) with B taken from its dense copy and from the compact values, with the default wave
-    quota and with the smallest one (64 tasks per wave: every window boundary, hub slices crossing quota boundaries, empty
-    wave ranges), against the oracle's exact-product numerics; the r1 kernel (BMSP_MAC_OLD) must agree on the same inputs."""
+    """the K = 32 block-MAC (tc_version 4) with B taken from its dense copy and from the compact values, and the direct kernel
+    (operand lines straight into the MFMA lanes, pairs of C tiles, no LDS; forced here on every task-count profile), with the
+    default wave quota and with the smallest one (64 tasks per wave: every window boundary, hub slices crossing quota
+    boundaries, empty wave ranges), against the oracle's exact-product numerics; the r1 kernel (BMSP_MAC_OLD) must agree on
+    the same inputs."""
     from pybmsp import gen
-    monkeypatch.setenv("BMSP_MAC_B_DENSE", b_dense)
+    if b_dense == "direct":
+        monkeypatch.setenv("BMSP_MAC_B_DENSE", "1")
+        monkeypatch.setenv("BMSP_MAC_DIRECT", "1")
+    else:
+        monkeypatch.setenv("BMSP_MAC_B_DENSE", b_dense)
+        monkeypatch.setenv("BMSP_MAC_DIRECT", "0")
     if quota:
         monkeypatch.setenv("BMSP_MAC_QUOTA", quota)
     exact = False
