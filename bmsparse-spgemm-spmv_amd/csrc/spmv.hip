@@ -635,6 +635,8 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
         tile[64 + lane] = A(0);
         const uint32_t n_item = vs_item_values(it);
         const bool single = MODE == kCached && vs_single(it);
+        const bool long_item = RED == kAtomic && it.num_items != 0;  // (in the kSorted kernels the eight sums cost registers the sort needs: 64 -> spills)
+        A acc8[8] = {A(0), A(0), A(0), A(0), A(0), A(0), A(0), A(0)};
 
         for (uint32_t base = it.blk_begin; base < it.blk_end;) {
             const bool first = MODE == kCached && base == it.blk_begin;
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
             }
             const uint32_t pos_first = (v_first - pos_base) * 2u;
 
-            if (RED == kAtomic) {
+            if (RED == kAtomic || long_item) {
                 for (uint32_t c0 = 0; c0 < nvals; c0 += 256u) {
                     A av[4], xv[4];
                     uint32_t rowl[4];
@@ -723,9 +725,20 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
                         rowl[u] = (ti >> 28) * 8u + (p >> 3);
                         xv[u] = Buf<T>::ld(rx, on ? ((ti & 0x0fffffffu) * 8u + (p & 7u)) * (uint32_t)sizeof(T) : kOob);
                     }
+                    if (long_item) {
+                        // a long block-row: every product belongs to one of EIGHT rows -- eight register sums per lane, folded once
+                        // per item, instead of 64 LDS float adds on eight addresses per instruction
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (c0 + 64u * (uint32_t)u + (uint32_t)lane < nvals) lds_add(tile + rowl[u], av[u] * xv[u]);
+                        for (int u = 0; u < 4; u++) {
+                            const A pr = c0 + 64u * (uint32_t)u + (uint32_t)lane < nvals ? av[u] * xv[u] : A(0);
+#pragma unroll
+                            for (int k = 0; k < 8; k++) acc8[k] += rowl[u] == (uint32_t)k ? pr : A(0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (c0 + 64u * (uint32_t)u + (uint32_t)lane < nvals) lds_add(tile + rowl[u], av[u] * xv[u]);
+                    }
                 }
             } else {
                 // the value's rank among the values of its row: integer LDS counter
@@ -802,7 +815,15 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
                     if (out0 + e < num_rows) y[out0 + e] = tile[e];
             } else {
                 // long row: park the partial sums, the last arriver folds them (same protocol as spmv_sweep_kernel)
-                if (lane < 8) __hip_atomic_store(&carry[(size_t)item_id * 8 + lane], tile[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                A mine = lane < 8 ? tile[lane & 7] : A(0);
+                if (long_item) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const A sk = wave_sum(acc8[k]);
+                        mine = lane == k ? sk : mine;
+                    }
+                }
+                if (lane < 8) __hip_atomic_store(&carry[(size_t)item_id * 8 + lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 uint32_t ticket = 0;
                 if (lane == 0) ticket = __hip_atomic_fetch_add(&counters[it.long_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
