@@ -497,7 +497,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, 8
 //      (experiments/lds_atomic_rate.hip), affordable at < 2 values per tile.  kSorted: the products are counting-sorted by row with
 //      INTEGER LDS atomics (full rate), run sums are taken with DPP steps, the last lane of a run adds to the tile with a plain
 //      read-modify-write.
-constexpr uint32_t kVsTiles = 128;  // tiles per batch at most (two per lane)
+#ifndef BMSP_VS_TILES
+#define BMSP_VS_TILES 128
+#endif
+#ifndef BMSP_VS_PRE
+#define BMSP_VS_PRE 4
+#endif
+constexpr uint32_t kVsTiles = BMSP_VS_TILES;  // tiles per batch at most
+constexpr int kVsTpl = (int)kVsTiles / 64;    // ... = tiles per lane
 constexpr uint32_t kVsVals = 512;   // values per batch at most
 constexpr int kVsChunks = kVsVals / 64;
 enum { kDecode = 0, kCached = 1, kBuild = 2 };
@@ -563,11 +570,11 @@ struct VsLds {
 
 // what a wave requests for an item before it works on it (kCached): the keys of its first 128 tiles, their end offsets unless the item is
 // a single batch, and entries + values of its first 256 values
-constexpr int kPre = 4;
+constexpr int kPre = BMSP_VS_PRE;
 template <typename A>
 struct VsPre {
-    uint64_t k0, k1;
-    uint32_t oe0, oe1;
+    uint64_t k[kVsTpl];
+    uint32_t oe[kVsTpl];
     uint32_t e[kPre];
     A a[kPre];
 };
@@ -582,14 +589,15 @@ template <typename T>
 __device__ __forceinline__ void vs_request(const SweepItem &it, int lane, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ offsets,
                                            rsrc_t rv, rsrc_t rp, uint32_t pos_base, VsPre<typename Acc<T>::type> &pre)
 {
-    const uint32_t b0 = it.blk_begin + (uint32_t)lane, b1 = b0 + 64u, bend = min(it.blk_begin + kVsTiles, it.blk_end);
-    pre.k0 = pre.k1 = (uint64_t)it.row_begin << 32;
-    pre.oe0 = pre.oe1 = 0;
-    if (b0 < bend) pre.k0 = keys[b0];
-    if (b1 < bend) pre.k1 = keys[b1];
-    if (!vs_single(it)) {
-        if (b0 < bend) pre.oe0 = (uint32_t)offsets[b0 + 1];
-        if (b1 < bend) pre.oe1 = (uint32_t)offsets[b1 + 1];
+    const uint32_t bend = min(it.blk_begin + kVsTiles, it.blk_end);
+    const bool single = vs_single(it);
+#pragma unroll
+    for (int t = 0; t < kVsTpl; t++) {
+        const uint32_t b = it.blk_begin + 64u * (uint32_t)t + (uint32_t)lane;
+        pre.k[t] = (uint64_t)it.row_begin << 32;
+        pre.oe[t] = 0;
+        if (b < bend) pre.k[t] = keys[b];
+        if (!single && b < bend) pre.oe[t] = (uint32_t)offsets[b + 1];
     }
     const uint32_t n_item = vs_item_values(it);
 #pragma unroll
@@ -640,59 +648,72 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
 
         for (uint32_t base = it.blk_begin; base < it.blk_end;) {
             const bool first = MODE == kCached && base == it.blk_begin;
-            const uint32_t b0 = base + (uint32_t)lane, b1 = base + 64u + (uint32_t)lane;
             const uint32_t bend = min(base + kVsTiles, it.blk_end);
-            uint64_t bm0 = 0, bm1 = 0, k0 = (uint64_t)it.row_begin << 32, k1 = k0;
-            uint32_t o0 = 0, o1 = 0, e0 = kOob, e1 = kOob;  // start / end of the tile's values, relative to the batch's first value
-            uint32_t v_first;
-            if (first) {
-                k0 = pre.k0;
-                k1 = pre.k1;
-                v_first = it.val_begin;
-                if (b0 < bend) e0 = single ? 0u : pre.oe0 - v_first;
-                if (b1 < bend) e1 = single ? 0u : pre.oe1 - v_first;
-            } else if (MODE == kCached) {
-                if (b0 < bend) { k0 = keys[b0]; e0 = (uint32_t)offsets[b0 + 1]; }
-                if (b1 < bend) { k1 = keys[b1]; e1 = (uint32_t)offsets[b1 + 1]; }
-                v_first = (uint32_t)offsets[base];
-                e0 -= v_first;
-                e1 -= v_first;
-            } else {
-                if (b0 < bend) { bm0 = bmps[b0]; k0 = keys[b0]; o0 = (uint32_t)offsets[b0]; }
-                if (b1 < bend) { bm1 = bmps[b1]; k1 = keys[b1]; o1 = (uint32_t)offsets[b1]; }
-                v_first = __builtin_amdgcn_readfirstlane(o0);
-                o0 -= v_first;
-                o1 -= v_first;
-                e0 = o0 + (uint32_t)__popcll(bm0);
-                e1 = o1 + (uint32_t)__popcll(bm1);
+            uint64_t bm[kVsTpl], kk[kVsTpl];
+            uint32_t ob[kVsTpl], eb[kVsTpl];  // start / end of the tile's values, relative to the batch's first value
+            uint32_t v_first = first ? it.val_begin : 0u;
+            if (MODE == kCached && !first) v_first = (uint32_t)offsets[base];
+#pragma unroll
+            for (int t = 0; t < kVsTpl; t++) {
+                const uint32_t b = base + 64u * (uint32_t)t + (uint32_t)lane;
+                bm[t] = 0; kk[t] = (uint64_t)it.row_begin << 32; ob[t] = 0; eb[t] = kOob;
+                if (first) {
+                    kk[t] = pre.k[t];
+                    if (b < bend) eb[t] = single ? 0u : pre.oe[t] - v_first;
+                } else if (MODE == kCached) {
+                    if (b < bend) { kk[t] = keys[b]; eb[t] = (uint32_t)offsets[b + 1] - v_first; }
+                } else {
+                    if (b < bend) { bm[t] = bmps[b]; kk[t] = keys[b]; ob[t] = (uint32_t)offsets[b]; }
+                }
+            }
+            if (MODE != kCached) {
+                v_first = __builtin_amdgcn_readfirstlane(ob[0]);
+#pragma unroll
+                for (int t = 0; t < kVsTpl; t++) {
+                    ob[t] -= v_first;
+                    eb[t] = ob[t] + (uint32_t)__popcll(bm[t]);  // lanes past the batch: 0 - v_first, far above the cut
+                }
             }
             // the batch: tiles whose values end inside the first kVsVals values (a prefix: offsets ascend; >= 8 tiles, a tile holds <= 64)
-            const bool ok0 = b0 < bend && e0 <= kVsVals, ok1 = b1 < bend && e1 <= kVsVals;
-            const uint32_t n0 = (uint32_t)__popcll(__ballot(ok0)), n1 = (uint32_t)__popcll(__ballot(ok1));
-            const uint32_t nb = n0 + n1;
-            const uint32_t nvals = single ? n_item
-                                          : (nb <= 64u ? (uint32_t)__builtin_amdgcn_readlane((int)e0, (int)(nb - 1u)) : (uint32_t)__builtin_amdgcn_readlane((int)e1, (int)(nb - 65u)));
+            bool ok[kVsTpl];
+            uint32_t nb = 0;
+#pragma unroll
+            for (int t = 0; t < kVsTpl; t++) {
+                ok[t] = base + 64u * (uint32_t)t + (uint32_t)lane < bend && eb[t] <= kVsVals;
+                nb += (uint32_t)__popcll(__ballot(ok[t]));
+            }
+            uint32_t nvals = n_item;
+            if (!single) {
+                uint32_t el = eb[0];
+#pragma unroll
+                for (int t = 1; t < kVsTpl; t++) el = (nb - 1u) >> 6 == (uint32_t)t ? eb[t] : el;
+                nvals = (uint32_t)__builtin_amdgcn_readlane((int)el, (int)((nb - 1u) & 63u));
+            }
             // tile slots: column and row-in-window of every tile of the batch
-            tinfo[lane] = key_col(k0) | ((key_row(k0) - it.row_begin) << 28);
-            tinfo[64 + lane] = key_col(k1) | ((key_row(k1) - it.row_begin) << 28);
+#pragma unroll
+            for (int t = 0; t < kVsTpl; t++) tinfo[64 * t + lane] = key_col(kk[t]) | ((key_row(kk[t]) - it.row_begin) << 28);
             if (RED == kSorted) {
                 cnt[lane] = 0;
                 cnt[64 + lane] = 0;
             }
             if (MODE != kCached) {
                 // entries from the bitmaps: {slot, position} of every stored value, at the value's index inside the batch
-                uint64_t m0 = ok0 ? bm0 : 0, m1 = ok1 ? bm1 : 0;
-                uint32_t i0 = o0, i1 = o1;
-                while (__any((m0 | m1) != 0)) {
-                    if (m0) {
-                        const uint32_t p = (uint32_t)__clzll((long long)m0);
-                        m0 &= ~(0x8000000000000000ull >> p);
-                        ent[i0++] = (uint16_t)(((uint32_t)lane << 6) | p);
-                    }
-                    if (m1) {
-                        const uint32_t p = (uint32_t)__clzll((long long)m1);
-                        m1 &= ~(0x8000000000000000ull >> p);
-                        ent[i1++] = (uint16_t)(((64u + (uint32_t)lane) << 6) | p);
+                uint64_t any = 0;
+#pragma unroll
+                for (int t = 0; t < kVsTpl; t++) {
+                    bm[t] = ok[t] ? bm[t] : 0;
+                    any |= bm[t];
+                }
+                while (__any(any != 0)) {
+                    any = 0;
+#pragma unroll
+                    for (int t = 0; t < kVsTpl; t++) {
+                        if (bm[t]) {
+                            const uint32_t p = (uint32_t)__clzll((long long)bm[t]);
+                            bm[t] &= ~(0x8000000000000000ull >> p);
+                            ent[ob[t]++] = (uint16_t)(((64u * (uint32_t)t + (uint32_t)lane) << 6) | p);
+                        }
+                        any |= bm[t];
                     }
                 }
             }
