@@ -94,7 +94,7 @@ __device__ __forceinline__ void scan_emit(const Out &o, uint64_t i, T ex, T, lon
     o(i, ex);
 }
 
-template <typename T, typename In, typename Out, int ITEMS>
+template <typename T, typename In, typename Out, int ITEMS, bool SUM_TILES = false>
 __global__ __launch_bounds__(kThreads) void scan_tile_down_kernel(In in, Out out, uint64_t n, const T *tile_excl,
                                                                   uint64_t tiles_per_block)
 {
@@ -102,7 +102,19 @@ __global__ __launch_bounds__(kThreads) void scan_tile_down_kernel(In in, Out out
     __shared__ T lds[4];
     // tile_excl == nullptr: a single workgroup walks all tiles with a running carry
     uint64_t first_tile = (uint64_t)blockIdx.x * tiles_per_block;
-    T carry = tile_excl ? tile_excl[first_tile] : T(0);
+    T carry = T(0);
+    if (tile_excl && SUM_TILES) {
+        // tile_excl holds the tiles' SUMS: the workgroup adds up the ones before it (few tiles: cheaper than a scan launch in between)
+        T part = 0;
+        for (uint64_t j = threadIdx.x; j < first_tile; j += kThreads) part += tile_excl[j];
+        part = wave_sum(part);
+        if (lane_id() == 0) lds[wave_id()] = part;
+        __syncthreads();
+        carry = lds[0] + lds[1] + lds[2] + lds[3];
+        __syncthreads();
+    } else if (tile_excl) {
+        carry = tile_excl[first_tile];
+    }
     for (uint64_t t = 0; t < tiles_per_block; t++) {
         uint64_t base = (first_tile + t) * kTileS;
         if (base >= n) break;
@@ -165,6 +177,13 @@ void device_exclusive_scan_impl(In in, Out out, uint64_t n, hipStream_t st)
     DevBuf<T> sums(tiles);
     hipLaunchKernelGGL((scan_tile_sums_kernel<T, In, ITEMS>), dim3((unsigned)tiles), dim3(kThreads), 0, st, in, n, sums.p);
     BMSP_CHECK_LAUNCH();
+    if (tiles <= 1024) {
+        // few tiles: every workgroup of the down pass adds the sums of the tiles before it itself -- two launches instead of three
+        hipLaunchKernelGGL((scan_tile_down_kernel<T, In, Out, ITEMS, true>), dim3((unsigned)tiles), dim3(kThreads), 0, st, in, out, n,
+                           (const T *)sums.p, (uint64_t)1);
+        BMSP_CHECK_LAUNCH();
+        return;
+    }
     device_exclusive_scan<T>(PtrIn<T>{sums.p}, PtrOut<T>{sums.p}, tiles, st);
     hipLaunchKernelGGL((scan_tile_down_kernel<T, In, Out, ITEMS>), dim3((unsigned)tiles), dim3(kThreads), 0, st, in, out, n,
                        (const T *)sums.p, (uint64_t)1);
