@@ -116,7 +116,10 @@ int bmsp_matrix_block_row_ptr(bmsp_matrix_t m, const uint32_t **d_rowptr, int64_
 
 /* Builds, ahead of the first product, the per-matrix structures the operators derive lazily and cache (none of them is part of
  * the reference's public state): `what` bit 0 = the SpMV sweep plan (the reference rebuilds its block-row pointer inside every
- * timed SpMV, src/bmSparse_SPMV.cu:199-206); bit 1 = the packed operand records of the SpGEMM block-MAC (both operand roles).
+ * timed SpMV, src/bmSparse_SPMV.cu:199-206) and, for matrices of sparse tiles, its position cache: one 16-bit {tile slot, position}
+ * entry per stored value (2 * nnz bytes of device memory; BMSP_SPMV_NO_POSCACHE=1 or a size above BMSP_SPMV_POSCACHE_MAX bytes,
+ * default 4 GiB, keeps the bitmap decode inside the kernel instead); bit 1 = the packed operand records of the SpGEMM block-MAC (both
+ * operand roles, incl. the dense fp16 tile copies of the MFMA kernels: 128 bytes per block).
  * Idempotent; asynchronous on `stream` except for the scalar read-backs of the plan. */
 #define BMSP_PREPARE_SPMV 1
 #define BMSP_PREPARE_SPGEMM 2
