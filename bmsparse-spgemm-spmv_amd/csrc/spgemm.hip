@@ -719,16 +719,21 @@ __device__ __forceinline__ bool tile_lane(uint64_t bmp_uniform, int lane, uint32
     return ((lane < 32 ? rlo : rhi) >> (lane & 31)) & 1u;
 }
 
-template <typename T, int G, int U>
+// DENSE (fp16 operands that carry the dense copy of their tiles, the one the MFMA kernels use): a tile is 128 contiguous bytes in position
+// order, so the element gathers, their rank arithmetic and the block records go away -- one 16-byte load per lane brings the A and B tiles
+// of FOUR tasks (lane = task u = l >> 4, operand (l >> 3) & 1, line l & 7) and one ds_write_b128 parks them; the k loop is unchanged.
+template <typename T, int G, int U, bool DENSE = false>
 __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const uint64_t *__restrict__ tasks, const uint32_t *__restrict__ task_begin,
                                                                         const uint32_t *__restrict__ a_meta, uint32_t a_meta_bytes,
                                                                         const T *__restrict__ a_vals, const uint32_t *__restrict__ b_meta,
                                                                         uint32_t b_meta_bytes, const T *__restrict__ b_vals,
                                                                         const uint64_t *__restrict__ c_bmps, const uint64_t *__restrict__ c_offs,
                                                                         typename MacOps<T>::Out *__restrict__ c_vals, uint32_t c_size, uint32_t a_bytes,
-                                                                        uint32_t b_bytes)
+                                                                        uint32_t b_bytes, const u32x4_t *__restrict__ a_dense = nullptr,
+                                                                        const u32x4_t *__restrict__ b_dense = nullptr)
 {
     using O = typename MacOps<T>::Out;
+    static_assert(!DENSE || (U == 4 && sizeof(T) == 2), "the dense staging maps 64 lanes onto 4 tasks x 2 operands x 8 lines of 8 halves");
     __shared__ __attribute__((aligned(16))) T tile_a[4][U][64];
     __shared__ __attribute__((aligned(16))) T tile_b[4][U][64];
     const int w = wave_id(), lane = lane_id();
@@ -755,7 +760,9 @@ __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const ui
         uint32_t m_aoff = 0, m_boff = 0;
         {
             const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)tbv2, 0), te = (uint32_t)__builtin_amdgcn_readlane((int)tbv2, G);
-            if (tb + lane < min(te, tb + 64u)) {
+            if (DENSE) {
+                m_abmp = tk2;  // the task word itself: tile indices are all the dense staging needs
+            } else if (tb + lane < min(te, tb + 64u)) {
                 load_block_meta(rma, (uint32_t)(tk2 >> 32), m_abmp, m_aoff);
                 load_block_meta(rmb, (uint32_t)tk2, m_bbmp, m_boff);
                 m_aoff *= (uint32_t)sizeof(T); m_boff *= (uint32_t)sizeof(T);
@@ -775,11 +782,26 @@ __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const ui
                     w_abmp = 0; w_bbmp = 0; w_aoff = 0; w_boff = 0;
                     if (t + lane < te) {
                         const uint64_t tk = tasks[t + lane];
-                        load_block_meta(rma, (uint32_t)(tk >> 32), w_abmp, w_aoff);
-                        load_block_meta(rmb, (uint32_t)tk, w_bbmp, w_boff);
-                        w_aoff *= (uint32_t)sizeof(T); w_boff *= (uint32_t)sizeof(T);
+                        if (DENSE) {
+                            w_abmp = tk;
+                        } else {
+                            load_block_meta(rma, (uint32_t)(tk >> 32), w_abmp, w_aoff);
+                            load_block_meta(rmb, (uint32_t)tk, w_bbmp, w_boff);
+                            w_aoff *= (uint32_t)sizeof(T); w_boff *= (uint32_t)sizeof(T);
+                        }
                     }
                 }
+                if constexpr (DENSE) {
+                    const int du = lane >> 4, op = (lane >> 3) & 1, line = lane & 7;
+                    const uint32_t src = min(t + (uint32_t)du - win_lo, 63u);
+                    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)w_abmp, (int)src, kWave), hi = (uint32_t)__shfl((int)(uint32_t)(w_abmp >> 32), (int)src, kWave);
+                    const bool on = t + (uint32_t)du < te;
+                    u32x4_t v = {0u, 0u, 0u, 0u};
+                    if (on) v = (op ? b_dense + (size_t)lo * 8 : a_dense + (size_t)hi * 8)[line];
+                    __builtin_amdgcn_wave_barrier();
+                    if (on) *(u32x4_t *)((op ? tile_b[w][du] : tile_a[w][du]) + line * 8) = v;  // A(i,k) at i*8+k, B(k,j) at j*8+k: the copies' own order
+                    __builtin_amdgcn_wave_barrier();
+                } else {
                 T av[U], bv[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -799,6 +821,7 @@ __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const ui
                     tile_b[w][u][lane] = bv[u];  // B column-major in the tile: B(k,j) at j*8+k
                 }
                 __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     if (t + u < te) {
@@ -838,6 +861,21 @@ void launch_mac_valu(const uint64_t *tasks, const uint32_t *task_begin, bmsp_mat
         ensure_block_meta(B, st);
         const uint32_t groups = (cs + kValuGroupC - 1) / kValuGroupC;
         uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
+        if constexpr (sizeof(T) == 2) {
+            // fp16: stage the tiles from their dense copies (BMSP_MAC_VALU_DENSE=0 keeps the element gathers; a copy above 4 GiB too)
+            const char *de = getenv("BMSP_MAC_VALU_DENSE");
+            const bool dense = de ? de[0] == '1' : ((uint64_t)A->block_num * 128 <= (4ull << 30) && (uint64_t)B->block_num * 128 <= (4ull << 30));
+            if (dense) {
+                ensure_dense_tiles(A, st);
+                ensure_dense_tiles(B, st);
+                hipLaunchKernelGGL((block_mac_valu_group_kernel<T, kValuGroupC, kValuBatch, true>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin,
+                                   A->block_meta, (uint32_t)(A->block_num * 16), (const T *)A->values, B->block_meta, (uint32_t)(B->block_num * 16),
+                                   (const T *)B->values, C->bmps, C->offsets, (typename MacOps<T>::Out *)C->values, cs, (uint32_t)a_bytes,
+                                   (uint32_t)b_bytes, (const u32x4_t *)A->dense_tiles, (const u32x4_t *)B->dense_tiles);
+                BMSP_CHECK_LAUNCH();
+                return;
+            }
+        }
         hipLaunchKernelGGL((block_mac_valu_group_kernel<T, kValuGroupC, kValuBatch>), dim3(grid), dim3(kThreads), 0, st, tasks, task_begin, A->block_meta,
                            (uint32_t)(A->block_num * 16), (const T *)A->values, B->block_meta, (uint32_t)(B->block_num * 16), (const T *)B->values,
                            C->bmps, C->offsets, (typename MacOps<T>::Out *)C->values, cs, (uint32_t)a_bytes, (uint32_t)b_bytes);
