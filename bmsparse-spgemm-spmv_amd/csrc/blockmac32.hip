@@ -34,16 +34,17 @@ namespace {
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
 // ---- dense-expanded tiles (cached per matrix) -------------------------------------------------------------------------
+template <typename T>
 struct ExpandDense {
     const uint64_t *bmps, *offsets;
-    const _Float16 *values;
-    _Float16 *out;
+    const T *values;
+    T *out;
     __device__ void operator()(uint64_t i) const
     {
         const uint64_t b = i >> 6;
         const int p = (int)(i & 63u);
         const uint64_t bm = bmps[b];
-        out[i] = tile_has(bm, p) ? values[offsets[b] + (uint64_t)tile_rank(bm, p)] : (_Float16)0;
+        out[i] = tile_has(bm, p) ? values[offsets[b] + (uint64_t)tile_rank(bm, p)] : (T)0;
     }
 };
 
@@ -466,10 +467,15 @@ __global__ void mfma32_selftest_kernel(float *d_out)
 void ensure_dense_tiles(bmsp_matrix_s *m, hipStream_t st)
 {
     if (m->dense_tiles) return;
-    if (m->dtype != BMSP_F16) fail(BMSP_ERR_INVALID, "dense fp16 tiles need an fp16 matrix");
-    m->dense_tiles = pool_alloc(128 * (size_t)(m->block_num ? m->block_num : 1) + 64);
-    if (m->block_num)
-        device_for_each(ExpandDense{m->bmps, m->offsets, (const _Float16 *)m->values, (_Float16 *)m->dense_tiles}, (uint64_t)m->block_num * 64, st);
+    // fp16: 128 B per block (the MFMA kernels' operand lines and the V15 staging); fp32: 256 B per block (V15 staging only)
+    if (m->dtype != BMSP_F16 && m->dtype != BMSP_F32) fail(BMSP_ERR_INVALID, "dense tile copies exist for fp16 and fp32 matrices");
+    const size_t es = dtype_size(m->dtype);
+    m->dense_tiles = pool_alloc(64 * es * (size_t)(m->block_num ? m->block_num : 1) + 64);
+    if (!m->block_num) return;
+    if (m->dtype == BMSP_F16)
+        device_for_each(ExpandDense<_Float16>{m->bmps, m->offsets, (const _Float16 *)m->values, (_Float16 *)m->dense_tiles}, (uint64_t)m->block_num * 64, st);
+    else
+        device_for_each(ExpandDense<float>{m->bmps, m->offsets, (const float *)m->values, (float *)m->dense_tiles}, (uint64_t)m->block_num * 64, st);
 }
 
 // true when the kernel can run this product (32-bit byte offsets into the dense copies and the records)

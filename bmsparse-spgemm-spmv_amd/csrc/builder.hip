@@ -418,6 +418,8 @@ void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st)
     ensure_block_meta(m, st);
     // K = 32 MFMA block-MAC: A (normal layout) is always read from its dense copy, B from the dense copy or from the records
     if (m->dtype == BMSP_F16 && m->block_num < (1ll << 25) && (!m->transposed || mac_mfma32_b_dense(m))) ensure_dense_tiles(m, st);
+    // V15 block-MAC (tc_version 5): fp32 operands with tiles at least a quarter full are staged from a dense copy too (256 B per block)
+    if (m->dtype == BMSP_F32 && m->nnz >= 16 * m->block_num && (uint64_t)m->block_num * 256 <= (4ull << 30)) ensure_dense_tiles(m, st);
 }
 
 bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, const int *d_rows, const int *d_cols,

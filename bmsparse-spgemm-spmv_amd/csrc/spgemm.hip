@@ -733,7 +733,7 @@ __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const ui
                                                                         const u32x4_t *__restrict__ b_dense = nullptr)
 {
     using O = typename MacOps<T>::Out;
-    static_assert(!DENSE || (U == 4 && sizeof(T) == 2), "the dense staging maps 64 lanes onto 4 tasks x 2 operands x 8 lines of 8 halves");
+    static_assert(!DENSE || (U == 4 && (sizeof(T) == 2 || sizeof(T) == 4)), "the dense staging maps 64 lanes onto (tasks) x 2 operands x (16-byte lines of a tile)");
     __shared__ __attribute__((aligned(16))) T tile_a[4][U][64];
     __shared__ __attribute__((aligned(16))) T tile_b[4][U][64];
     const int w = wave_id(), lane = lane_id();
@@ -792,14 +792,26 @@ __global__ __launch_bounds__(kThreads) void block_mac_valu_group_kernel(const ui
                     }
                 }
                 if constexpr (DENSE) {
-                    const int du = lane >> 4, op = (lane >> 3) & 1, line = lane & 7;
-                    const uint32_t src = min(t + (uint32_t)du - win_lo, 63u);
-                    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)w_abmp, (int)src, kWave), hi = (uint32_t)__shfl((int)(uint32_t)(w_abmp >> 32), (int)src, kWave);
-                    const bool on = t + (uint32_t)du < te;
-                    u32x4_t v = {0u, 0u, 0u, 0u};
-                    if (on) v = (op ? b_dense + (size_t)lo * 8 : a_dense + (size_t)hi * 8)[line];
+                    // a tile is 64 / EPL lines of 16 bytes: 8 (fp16) or 16 (fp32); one load instruction brings 64 / (2 LPT) tasks
+                    constexpr int EPL = 16 / (int)sizeof(T), LPT = 64 / EPL, TPLD = 64 / (2 * LPT), ROUNDS = U / TPLD;
+                    const int op = (lane / LPT) & 1, line = lane % LPT;
+                    u32x4_t v[ROUNDS];
+                    bool on[ROUNDS];
+#pragma unroll
+                    for (int q = 0; q < ROUNDS; q++) {
+                        const uint32_t du = (uint32_t)(q * TPLD + lane / (2 * LPT));
+                        const uint32_t src = min(t + du - win_lo, 63u);
+                        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)w_abmp, (int)src, kWave), hi = (uint32_t)__shfl((int)(uint32_t)(w_abmp >> 32), (int)src, kWave);
+                        on[q] = t + du < te;
+                        v[q] = u32x4_t{0u, 0u, 0u, 0u};
+                        if (on[q]) v[q] = (op ? b_dense + (size_t)lo * LPT : a_dense + (size_t)hi * LPT)[line];
+                    }
                     __builtin_amdgcn_wave_barrier();
-                    if (on) *(u32x4_t *)((op ? tile_b[w][du] : tile_a[w][du]) + line * 8) = v;  // A(i,k) at i*8+k, B(k,j) at j*8+k: the copies' own order
+#pragma unroll
+                    for (int q = 0; q < ROUNDS; q++) {
+                        const int du = q * TPLD + lane / (2 * LPT);
+                        if (on[q]) *(u32x4_t *)((op ? tile_b[w][du] : tile_a[w][du]) + line * EPL) = v[q];  // A(i,k) at i*8+k, B(k,j) at j*8+k: the copies' own order
+                    }
                     __builtin_amdgcn_wave_barrier();
                 } else {
                 T av[U], bv[U];
@@ -861,10 +873,16 @@ void launch_mac_valu(const uint64_t *tasks, const uint32_t *task_begin, bmsp_mat
         ensure_block_meta(B, st);
         const uint32_t groups = (cs + kValuGroupC - 1) / kValuGroupC;
         uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
-        if constexpr (sizeof(T) == 2) {
-            // fp16: stage the tiles from their dense copies (BMSP_MAC_VALU_DENSE=0 keeps the element gathers; a copy above 4 GiB too)
+        if constexpr (sizeof(T) == 2 || sizeof(T) == 4) {
+            // fp16 / fp32: stage the tiles from their dense copies (64 elements per block: 128 / 256 B; BMSP_MAC_VALU_DENSE=0 keeps the element
+            // gathers, and so does a copy above 4 GiB)
             const char *de = getenv("BMSP_MAC_VALU_DENSE");
-            const bool dense = de ? de[0] == '1' : ((uint64_t)A->block_num * 128 <= (4ull << 30) && (uint64_t)B->block_num * 128 <= (4ull << 30));
+            const uint64_t per_block = 64 * sizeof(T);
+            // fp16 copies exist anyway (the MFMA kernels' operands).  An fp32 copy is 256 B per block: taken when the tiles are at least a
+            // quarter full (the copy is then <= 4x the values; FEM-like 3.7 values per tile: 17x the memory for -10 % of T_7, not taken)
+            const bool worth = sizeof(T) == 2 || (A->nnz >= 16 * A->block_num && B->nnz >= 16 * B->block_num);
+            const bool dense = de ? de[0] == '1'
+                                  : (worth && (uint64_t)A->block_num * per_block <= (4ull << 30) && (uint64_t)B->block_num * per_block <= (4ull << 30));
             if (dense) {
                 ensure_dense_tiles(A, st);
                 ensure_dense_tiles(B, st);

@@ -452,6 +452,32 @@ def test_mfma_16x16x32_lane_layout(bmsp):
     assert bad.value == 0
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("staging", ["0", "1"])
+@pytest.mark.parametrize("case", ["rmat", "banded_full", "hub_c_blocks", "rect_ragged"])
+def test_valu_block_mac_staging(oracle, bmsp, monkeypatch, case, staging, dtype):
+    """tc_version 5 (V15 numerics: k order inside a task, tasks in list order) with the tiles staged from the dense copies (16-byte
+    lines, four fp16 / two fp32 tasks per load) and with the element gathers: both bit-exact against the oracle, fp32 and fp16."""
+    from pybmsp import gen
+    monkeypatch.setenv("BMSP_MAC_VALU_DENSE", staging)
+    if case == "rmat":
+        n, _, r, c, v = gen.rmat(11, 8)
+        A = Bc = (n, n, r, c, v)
+    elif case == "banded_full":
+        n, _, r, c, v = gen.banded(515, 20)
+        A = Bc = (n, n, r, c, np.round(v * 8) / 8)
+    elif case == "hub_c_blocks":
+        nk = 8 * 300  # C blocks with hundreds of tasks: the 64-task windows of a hub group are refetched in place
+        r = np.repeat(np.arange(16), nk); c = np.tile(np.arange(nk), 16)
+        A = (16, nk, r, c, ((r * 7 + c) % 5 - 2).astype(np.float64))
+        Bc = (nk, 16, c, r, ((c * 3 + r) % 7 - 3).astype(np.float64))
+    else:
+        _, _, r1, c1, v1 = gen.random_coo(203, 77, 2500, seed=5, integer=True)
+        _, _, r2, c2, v2 = gen.random_coo(77, 331, 3000, seed=6, integer=True)
+        A, Bc = (203, 77, r1, c1, v1), (77, 331, r2, c2, v2)
+    check_spgemm(oracle, bmsp, A, Bc, dtype, 0, 5)
+
+
 @pytest.mark.parametrize("b_dense", ["0", "1", "direct"])
 @pytest.mark.parametrize("quota", ["64", ""])
 @pytest.mark.parametrize("case", ["rmat", "banded_full", "hub_c_blocks", "rect_ragged", "ragusa"])
