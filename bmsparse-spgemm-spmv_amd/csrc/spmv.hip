@@ -4,11 +4,14 @@
 // block-row, one lane per tile ELEMENT, serial loop over the row's tiles) and spmv_kernel_new (:84-150, the "batched"
 // path: several tiles per step, wide lane reduction).  Both rebuild a block-row pointer on every call (:199-206).
 //
-// MI355X design (variant 0, the default): the block-vector sweep.
+// MI355X design (variant 0, the default): the block-vector sweep over a cached plan.  Three kernels share the plan; the launcher picks by
+// the matrix: spmv_vstream_kernel (lane per stored value; matrices of sparse tiles -- see its own header below), spmv_rowgroup_kernel
+// (16 lanes per block-row, 16-byte value loads; >= 16 values per tile and no hub block-row), spmv_sweep_kernel (lane per tile, described
+// here; since round 2 only its FULL-tile variant runs by default, BMSP_SPMV_OLD=1 brings the whole kernel back).
 //   * A per-matrix SWEEP PLAN (built once, cached like the block-row pointer) cuts the block array into wave-sized
 //     work items.  Short block-rows are grouped into items aligned to block-row boundaries (<= 16 block-rows inside
-//     one aligned 16-row window, < 512 tiles), so an item owns a contiguous slice of u outright.  A block-row with
-//     more than 256 tiles (hub rows of web / R-MAT graphs) is cut into 256-tile items of its own.
+//     one aligned 16-row window, < 512 tiles; ~96 tiles for the value-stream kernel), so an item owns a contiguous slice of u outright.
+//     A block-row with more than 256 tiles (hub rows of web / R-MAT graphs) is cut into 256-tile items of its own.
 //   * One wave per item.  Lane l loads key / bitmap / offset of tiles l and l+64 of a 128-tile batch: three fully
 //     coalesced streams, no dependent pointer chase.  Work per lane is one tile whatever the row lengths are, so
 //     skewed graphs stay balanced.
