@@ -14,6 +14,7 @@
 // Every path produces a permutation; values move once, through one gather (as bb_segsort does, bb_comput_s.h:88).
 #include "matrix.h"
 #include "prims.hip.h"
+#include <cstdlib>
 
 namespace bmsp {
 namespace {
@@ -515,7 +516,7 @@ bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals,
     // (moving the payload inside the sort kernels -- no permutation array, no gather pass -- was measured: T_5 605 -> 983 us on the
     // FEM-like product; E scattered 8-byte gathers per lane at 3 waves per SIMD are slower than one fully parallel gather pass)
     DevBuf<uint32_t> perm(n);
-    const bool narrow = jbits + (int)kTaskBlockIdxBits <= 32;
+    const bool narrow = jbits + (int)kTaskBlockIdxBits <= 32 && !getenv("BMSP_SEGSORT_WIDE");  // the variable forces the 64-bit sort words (tests)
     const bool ok = narrow ? segsort_tasks_lds<uint32_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st)
                            : segsort_tasks_lds<uint64_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st);
     if (!ok) return false;  // hub rows: caller takes the global sort

@@ -452,6 +452,18 @@ def test_mfma_16x16x32_lane_layout(bmsp):
     assert bad.value == 0
 
 
+def test_segmented_task_sort_wide_words(oracle, bmsp, monkeypatch):
+    """the register segment sort with 64-bit sort words (products whose C has more than 2^20 block columns use them; forced here):
+    segments of every size class (2 .. 64 words per lane would need > 2048 tasks per block-row: the rmat case reaches the 16 / 32
+    classes, the hub case the LDS block kernel), structure and values against the oracle."""
+    from pybmsp import gen
+    monkeypatch.setenv("BMSP_SEGSORT_WIDE", "1")
+    n, _, r, c, v = gen.rmat(11, 8)
+    st = check_spgemm(oracle, bmsp, (n, n, r, c, v), (n, n, r, c, v), 0, 1, 5)
+    n, _, r, c, v = gen.banded(2000, 40)
+    check_spgemm(oracle, bmsp, (n, n, r, c, v), (n, n, r, c, v), 0, 1, 5)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("staging", ["0", "1"])
 @pytest.mark.parametrize("case", ["rmat", "banded_full", "hub_c_blocks", "rect_ragged"])
