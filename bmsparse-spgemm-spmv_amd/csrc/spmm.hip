@@ -15,6 +15,7 @@
 // plan; their partial rows go through a carry slot and the last wave to arrive folds them in item order (same
 // write-through store + agent-scope counter hand-off as the SpMV, so the result does not depend on arrival order).
 #include "spmv_plan.h"
+#include <cstdlib>
 #include "prims.hip.h"
 
 namespace bmsp {
@@ -277,6 +278,131 @@ __global__ __launch_bounds__(kThreads) void spmm_wide_kernel(const SweepItem *__
     }
 }
 
+// ---- k <= 8 on matrices that carry the SpMV position cache: the value-stream walk of spmv.hip, KK products per stored value ---------
+// One wave (= one workgroup) per plan item and chunk of KK vectors.  The tile phase and the batch cut are those of spmv_vstream_kernel
+// (the cached entries number their tile slots inside exactly these batches: <= 128 tiles holding <= 512 values); the value phase loads, per
+// stored value, its entry, its value (both coalesced) and KK consecutive X entries of its column (row-major X: one 16-byte request per
+// four vectors when X allows it), and adds the KK products into the item's u tile (16 block-rows x 8 rows x KK) with LDS float adds.
+// The slot kernel above walks a tile's elements serially per lane group; here every lane of every request has an element.
+typedef uint32_t u32x4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t spmm_rsrc(const void *p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+constexpr uint32_t kSmTiles = 128, kSmVals = 512;  // the batch cut of the position cache (spmv.hip: kVsTiles, kVsVals)
+
+template <typename T, int KK>
+__global__ __launch_bounds__(64) void spmm_vstream_kernel(const SweepItem *__restrict__ items, const uint64_t *__restrict__ keys,
+                                                          const uint64_t *__restrict__ offsets, const T *__restrict__ values,
+                                                          const uint16_t *__restrict__ pos, uint32_t pos_base, uint32_t pos_count,
+                                                          uint32_t values_bytes, const T *__restrict__ X, typename Acc<T>::type *__restrict__ Y,
+                                                          typename Acc<T>::type *__restrict__ carry, uint32_t *__restrict__ counters,
+                                                          uint32_t num_rows, uint32_t num_cols, uint32_t k, uint64_t ldx, uint64_t ldy, int x_vec)
+{
+    using A = typename Acc<T>::type;
+    constexpr uint32_t kOobS = 0xffffffffu;
+    __shared__ A tile[kItemRows * 8 * KK];
+    __shared__ uint32_t tinfo[kSmTiles];
+    const int lane = lane_id();
+    const uint32_t item_id = blockIdx.x, j0 = blockIdx.y * KK;
+    const SweepItem it = items[item_id];
+    const __amdgpu_buffer_rsrc_t rp = spmm_rsrc(pos, pos_count * 2u), rv = spmm_rsrc(values, values_bytes);
+    for (uint32_t e = (uint32_t)lane; e < kItemRows * 8 * KK; e += 64) tile[e] = A(0);
+
+    for (uint32_t base = it.blk_begin; base < it.blk_end;) {
+        const uint32_t b0 = base + (uint32_t)lane, b1 = b0 + 64u, bend = min(base + kSmTiles, it.blk_end);
+        uint64_t k0 = (uint64_t)it.row_begin << 32, k1 = k0;
+        uint32_t e0 = kOobS, e1 = kOobS;
+        const uint32_t v_first = (uint32_t)offsets[base];
+        if (b0 < bend) { k0 = keys[b0]; e0 = (uint32_t)offsets[b0 + 1] - v_first; }
+        if (b1 < bend) { k1 = keys[b1]; e1 = (uint32_t)offsets[b1 + 1] - v_first; }
+        const bool ok0 = b0 < bend && e0 <= kSmVals, ok1 = b1 < bend && e1 <= kSmVals;
+        const uint32_t nb = (uint32_t)__popcll(__ballot(ok0)) + (uint32_t)__popcll(__ballot(ok1));
+        const uint32_t nvals = nb <= 64u ? (uint32_t)__builtin_amdgcn_readlane((int)e0, (int)(nb - 1u)) : (uint32_t)__builtin_amdgcn_readlane((int)e1, (int)(nb - 65u));
+        tinfo[lane] = key_col(k0) | ((key_row(k0) - it.row_begin) << 28);
+        tinfo[64 + lane] = key_col(k1) | ((key_row(k1) - it.row_begin) << 28);
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t c0 = 0; c0 < nvals; c0 += 64u) {
+            const uint32_t idx = c0 + (uint32_t)lane;
+            const bool on = idx < nvals;
+            const uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rp, on ? (v_first - pos_base + idx) * 2u : kOobS, 0, 0);
+            A av;
+            if (sizeof(T) == 4) av = (A)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, on ? (v_first + idx) * 4u : kOobS, 0, 0));
+            else av = on ? (A)values[v_first + idx] : A(0);
+            const uint32_t ti = tinfo[e >> 6], p = e & 63u;
+            const uint32_t row = (ti >> 28) * 8u + (p >> 3), col = (ti & 0x0fffffffu) * 8u + (p & 7u);
+            const bool live = on && col < num_cols;
+            A xv[KK];
+            const T *xr = X + (uint64_t)col * ldx + j0;
+            if (sizeof(T) == 4 && x_vec) {
+                // X is 16-byte aligned with ldx a multiple of 4 floats, and the chunk's vectors all exist: one request per four vectors
+                const float4 *xq = reinterpret_cast<const float4 *>(xr);
+#pragma unroll
+                for (int q = 0; q < KK / 4; q++) {
+                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (live) w = xq[q];
+                    xv[4 * q + 0] = (A)w.x;
+                    xv[4 * q + 1] = (A)w.y;
+                    xv[4 * q + 2] = (A)w.z;
+                    xv[4 * q + 3] = (A)w.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < KK; q++) xv[q] = (live && j0 + (uint32_t)q < k) ? (A)xr[q] : A(0);
+            }
+            if (on) {
+#pragma unroll
+                for (int q = 0; q < KK; q++) __hip_atomic_fetch_add(&tile[row * KK + (uint32_t)q], av * xv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        base += nb;
+    }
+
+    if (it.num_items == 0) {
+        const uint32_t n_out = (it.row_end - it.row_begin) * 8u * KK, out0 = it.row_begin * 8u;
+        for (uint32_t e = (uint32_t)lane; e < n_out; e += 64) {
+            const uint32_t row = out0 + e / KK, j = j0 + e % KK;
+            if (row < num_rows && j < k) Y[(uint64_t)row * ldy + j] = tile[e];
+        }
+        return;
+    }
+    // hub block-row: park the 8 x KK partial sums, the last arriver of this (row, vector chunk) folds them in item order
+    const size_t slot = ((size_t)item_id * gridDim.y + blockIdx.y) * 8 * KK;
+    for (uint32_t e = (uint32_t)lane; e < 8u * KK; e += 64) __hip_atomic_store(&carry[slot + e], tile[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t ticket = 0;
+    uint32_t *cnt = counters + (size_t)it.long_idx * gridDim.y + blockIdx.y;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != it.num_items - 1) return;
+    for (uint32_t e = (uint32_t)lane; e < 8u * KK; e += 64) {
+        A sum = A(0);
+        for (uint32_t c = 0; c < it.num_items; c++)
+            sum += __hip_atomic_load(&carry[((size_t)(it.first_item + c) * gridDim.y + blockIdx.y) * 8 * KK + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t row = it.row_begin * 8u + e / KK, j = j0 + e % KK;
+        if (row < num_rows && j < k) Y[(uint64_t)row * ldy + j] = sum;
+    }
+}
+
+template <typename T, int KK>
+void launch_vstream(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, int k, hipStream_t st)
+{
+    using Ac = typename Acc<T>::type;
+    const uint32_t n_items = (uint32_t)A->spmv_num_chunks;
+    const uint32_t chunks = (uint32_t)((k + KK - 1) / KK);
+    DevBuf<Ac> carry(A->spmv_plan_long ? (size_t)n_items * chunks * 8 * KK : 1);
+    DevBuf<uint32_t> counters((size_t)(A->spmv_plan_long ? A->spmv_plan_long : 1) * chunks);
+    BMSP_HIP(hipMemsetAsync(counters.p, 0, 4 * counters.n, st));
+    const int x_vec = sizeof(T) == 4 && ((uintptr_t)X & 15u) == 0 && ldx % 4 == 0 && k % KK == 0;
+    hipLaunchKernelGGL((spmm_vstream_kernel<T, KK>), dim3(n_items, chunks), dim3(64), 0, st, plan_items(A), A->keys, A->offsets, (const T *)A->values,
+                       A->spmv_pos, (uint32_t)A->spmv_pos_base, (uint32_t)A->spmv_pos_count, (uint32_t)((size_t)A->values_extent() * sizeof(T)),
+                       (const T *)X, (Ac *)Y, carry.p, counters.p, (uint32_t)A->num_rows, (uint32_t)A->num_cols, (uint32_t)k, (uint64_t)ldx,
+                       (uint64_t)ldy, x_vec);
+    BMSP_CHECK_LAUNCH();
+    if (A->spmv_plan_long) BMSP_HIP(hipStreamSynchronize(st));  // the carry slots go back to the pool on return
+}
+
 template <typename T>
 void launch_wide(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, int k, hipStream_t st)
 {
@@ -315,6 +441,12 @@ void launch(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, 
 {
     // measured on the webbase-1M-like case: the time is set by tiles x vector chunks (each wave walks its tiles
     // serially), so the widest lane group that k fills wins
+    // k <= 8 on a matrix that carries the SpMV position cache (sparse tiles): the value-stream walk
+    if (A->spmv_pos && k <= 8 && !getenv("BMSP_SPMM_NO_VSTREAM")) {
+        if (k <= 4) launch_vstream<T, 4>(A, X, ldx, Y, ldy, k, st);
+        else launch_vstream<T, 8>(A, X, ldx, Y, ldy, k, st);
+        return;
+    }
     if (k <= 4) launch_kk<T, 4>(A, X, ldx, Y, ldy, k, st);
     else if (k <= 16) launch_kk<T, 16>(A, X, ldx, Y, ldy, k, st);
     else if ((uint64_t)A->values_extent() < (1ull << 32)) launch_wide<T>(A, X, ldx, Y, ldy, k, st);  // 32-bit value indices in the stream
@@ -329,8 +461,13 @@ void spmm(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, in
     if (k < 1) fail(BMSP_ERR_INVALID, "k must be >= 1");
     if (ldx < k || ldy < k) fail(BMSP_ERR_INVALID, "leading dimensions must be >= k");
     if (A->num_rows == 0) return;
+    if (k == 1 && ldx == 1 && ldy == 1) {  // one contiguous vector: the SpMV itself
+        spmv(A, X, Y, BMSP_SPMV_DEFAULT, st);
+        return;
+    }
     ensure_rowptr(A, st);
     build_plan(A, st);
+    prepare_spmv(A, st);  // + the position cache, for matrices the value-stream kernels take
     switch (A->dtype) {
     case BMSP_F32: launch<float>(A, X, ldx, Y, ldy, k, st); break;
     case BMSP_F16: launch<_Float16>(A, X, ldx, Y, ldy, k, st); break;
