@@ -392,6 +392,30 @@ void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st)
 }
 
 namespace {
+struct RowMaxBlocks {
+    const uint32_t *rowptr;
+    uint32_t *out;
+    __device__ void operator()(uint64_t r) const
+    {
+        atomicMax(out, rowptr[r + 1] - rowptr[r]);  // once per matrix
+    }
+};
+}  // namespace
+
+// most blocks in one block-row, once per matrix (one small reduction and a read-back the first time)
+void ensure_row_stats(bmsp_matrix_s *m, hipStream_t st)
+{
+    if (m->max_row_blocks >= 0) return;
+    ensure_rowptr(m, st);
+    const int64_t nbr = m->num_block_rows();
+    if (nbr == 0) { m->max_row_blocks = 0; return; }
+    DevBuf<uint32_t> mx(1);
+    BMSP_HIP(hipMemsetAsync(mx.p, 0, 4, st));
+    device_for_each(RowMaxBlocks{m->rowptr, mx.p}, (uint64_t)nbr, st);
+    m->max_row_blocks = (int64_t)read_back(mx.p, st);
+}
+
+namespace {
 struct PackBlockMeta {
     const uint64_t *bmps, *offsets;
     uint32_t *meta;

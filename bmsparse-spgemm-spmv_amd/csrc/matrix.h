@@ -20,6 +20,7 @@ struct bmsp_matrix_s {
     // derived, built lazily and cached (never part of the reference's public state)
     uint32_t *rowptr = nullptr;   // dense block-row pointer, num_block_rows()+1 entries
     int64_t rowptr_rows = 0;
+    int64_t max_row_blocks = -1;  // most blocks in one block-row (ensure_row_stats; bounds the SpGEMM's task segments without a read-back)
     // sweep plan of the SpMV (see spmv.hip): chunk descriptors
     uint32_t *spmv_chunks = nullptr;
     int64_t spmv_num_chunks = 0;
@@ -74,6 +75,7 @@ bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, co
                                      const double *d_vals, int transposed, bmsp_dtype dtype, hipStream_t st);
 
 void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st);
+void ensure_row_stats(bmsp_matrix_s *m, hipStream_t st);
 void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st);
 void ensure_dense_tiles(bmsp_matrix_s *m, hipStream_t st);
 bool mac_mfma32_supported(const bmsp_matrix_s *A, const bmsp_matrix_s *B);
@@ -101,7 +103,8 @@ template <typename T>
 struct PingPong;
 // stable sort of (key, task) pairs inside the runs of equal (key >> jbits): the SpGEMM's segmented path
 // false = some block-row has more tasks than the LDS paths hold; nothing was modified and the caller sorts globally
-bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st);
+bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st, uint64_t max_seg_bound = 0,
+                             uint64_t seg_count_bound = 0);
 void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const int *d_segs, int64_t num_segs,
                  hipStream_t st);
 

@@ -306,10 +306,15 @@ struct EmitRunStarts {
     uint64_t n;
     int shift;
     int *segs;
-    uint32_t *count;
+    uint32_t *count;      // pinned host scalar (the general path reads it back)
+    uint32_t *count_dev;  // device copy (the read-back-free path's kernels test their segment index against it)
     __device__ void operator()(uint64_t i, uint32_t ex, uint32_t is_head) const
     {
-        if (i == n) { *count = ex; return; }
+        if (i == n) {
+            if (count) *count = ex;
+            if (count_dev) *count_dev = ex;
+            return;
+        }
         if (is_head) segs[ex] = (int)i;  // RunHead's value for this element
     }
 };
@@ -471,6 +476,29 @@ __global__ __launch_bounds__(kThreads) void segsort_tasks_wave_kernel(uint64_t *
     else if constexpr (sizeof(W) == 4) sort_task_segment_regs<W, 64, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);  // 64 words per lane
 }
 
+// the same sort without segment lists: wave i takes segment i of the run-start array.  For products whose block-row segments are known
+// to fit a wave BEFORE the tasks exist (most blocks per block-row of A x most blocks per block-row of B <= 4096), so that neither the
+// segment count nor the class counts have to travel to the host: the grid is sized by A's block-rows, surplus waves leave.
+template <typename W>
+__global__ __launch_bounds__(kThreads) void segsort_tasks_direct_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, const int *__restrict__ segs,
+                                                                        const uint32_t *__restrict__ nseg_dev, uint64_t n, uint64_t col_mask)
+{
+    const uint32_t s = blockIdx.x * 4 + (uint32_t)wave_id();
+    const uint32_t nseg = *nseg_dev;
+    if (s >= nseg) return;
+    const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hi - lo));
+    const int lane = lane_id();
+    if (len == 1) {
+        if (lane == 0) perm[lo] = (uint32_t)lo;
+    } else if (len <= 128) sort_task_segment_regs<W, 2, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else if (len <= 256) sort_task_segment_regs<W, 4, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else if (len <= 512) sort_task_segment_regs<W, 8, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else if (len <= 1024) sort_task_segment_regs<W, 16, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else if (len <= 2048) sort_task_segment_regs<W, 32, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else if constexpr (sizeof(W) == 4) sort_task_segment_regs<W, 64, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+}
+
 template <typename W>
 __global__ __launch_bounds__(512) void segsort_tasks_block_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, const int *__restrict__ segs,
                                                                   uint32_t nseg, uint64_t n, const uint32_t *__restrict__ list, uint64_t col_mask)
@@ -504,19 +532,38 @@ bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *se
     return true;
 }
 
-bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st)
+bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st, uint64_t max_seg_bound,
+                             uint64_t seg_count_bound)
 {
     if (n >= (1ull << 31)) return false;
     // segments = runs of equal block-row (reference: :982-1004).  Inside a run the row part of the packed key is
     // constant, so comparing whole keys orders by column: no masking pass is needed.
     DevBuf<int> segs(n);
-    HostScalar<uint32_t> cnt;
-    device_exclusive_scan<uint32_t>(RunHead{keys.cur, n, jbits}, EmitRunStarts{keys.cur, n, jbits, segs.p, cnt.dev()}, n + 1, st);
-    const uint32_t nseg = cnt.wait(st);
+    const bool narrow = jbits + (int)kTaskBlockIdxBits <= 32 && !getenv("BMSP_SEGSORT_WIDE");  // the variable forces the 64-bit sort words (tests)
+    const uint64_t col_mask = (1ull << jbits) - 1ull;
     // (moving the payload inside the sort kernels -- no permutation array, no gather pass -- was measured: T_5 605 -> 983 us on the
     // FEM-like product; E scattered 8-byte gathers per lane at 3 waves per SIMD are slower than one fully parallel gather pass)
     DevBuf<uint32_t> perm(n);
-    const bool narrow = jbits + (int)kTaskBlockIdxBits <= 32 && !getenv("BMSP_SEGSORT_WIDE");  // the variable forces the 64-bit sort words (tests)
+    const uint64_t wave_cap = narrow ? 2 * kTaskWaveMax : kTaskWaveMax;
+    if (max_seg_bound && max_seg_bound <= wave_cap && seg_count_bound && !getenv("BMSP_SEGSORT_READBACK")) {
+        // every segment fits one wave, known from the operands alone: no segment lists, no count on the host
+        DevBuf<uint32_t> nseg_dev(1);
+        device_exclusive_scan<uint32_t>(RunHead{keys.cur, n, jbits}, EmitRunStarts{keys.cur, n, jbits, segs.p, nullptr, nseg_dev.p}, n + 1, st);
+        const uint64_t waves = std::min<uint64_t>(seg_count_bound, n);
+        if (narrow)
+            hipLaunchKernelGGL((segsort_tasks_direct_kernel<uint32_t>), dim3((unsigned)((waves + 3) / 4)), dim3(kThreads), 0, st, keys.cur, perm.p, segs.p,
+                               nseg_dev.p, n, col_mask);
+        else
+            hipLaunchKernelGGL((segsort_tasks_direct_kernel<uint64_t>), dim3((unsigned)((waves + 3) / 4)), dim3(kThreads), 0, st, keys.cur, perm.p, segs.p,
+                               nseg_dev.p, n, col_mask);
+        BMSP_CHECK_LAUNCH();
+        device_for_each(GatherVals<uint64_t>{vals.cur, perm.p, vals.alt}, n, st);
+        vals.flip();
+        return true;
+    }
+    HostScalar<uint32_t> cnt;
+    device_exclusive_scan<uint32_t>(RunHead{keys.cur, n, jbits}, EmitRunStarts{keys.cur, n, jbits, segs.p, cnt.dev(), nullptr}, n + 1, st);
+    const uint32_t nseg = cnt.wait(st);
     const bool ok = narrow ? segsort_tasks_lds<uint32_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st)
                            : segsort_tasks_lds<uint64_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st);
     if (!ok) return false;  // hub rows: caller takes the global sort

@@ -933,8 +933,10 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     StageTimer tm(st, timing);
     tm.mark(-1);
 
-    // T_1: blocks per block-row of B (cached dense pointer)
+    // T_1: blocks per block-row of B (cached dense pointer; the per-matrix row maxima are cached with it)
     ensure_rowptr(B, st);
+    ensure_row_stats(A, st);
+    ensure_row_stats(B, st);
     tm.mark(1);
 
     // T_2 + T_3 (first half): fan-out per A block and its exclusive scan
@@ -1016,7 +1018,10 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     const bool try_segmented = mode == BMSP_SORT_SEGMENTED || (mode == BMSP_SORT_AUTO && avg_seg >= 4 && avg_seg <= 2048);
     S->sort_path = 0;
     if (n_tasks) {
-        if (try_segmented && segsort_tasks_by_column(kk, vv, n_tasks, jbits, st)) {
+        // a block-row of C collects at most (most blocks in a block-row of A) x (most blocks in a block-row of B) tasks: when that fits a
+        // wave's register sort, T_5 runs without a single read-back (per-matrix maxima, cached: ensure_row_stats)
+        const uint64_t seg_bound = (uint64_t)std::max<int64_t>(A->max_row_blocks, 0) * (uint64_t)std::max<int64_t>(B->max_row_blocks, 0);
+        if (try_segmented && segsort_tasks_by_column(kk, vv, n_tasks, jbits, st, seg_bound, a_block_rows)) {
             S->sort_path = 1;
             tm.mark(8);
         } else {
