@@ -381,6 +381,22 @@ void free_matrix(bmsp_matrix_s *m)
     delete m;
 }
 
+// Drops what the operators derived from the arrays and cached on the handle (bmsp_matrix_invalidate).  Value-derived: the dense tile
+// copies of the block-MAC kernels.  Structure-derived: block-row pointer and row maxima, SpMV plan and position cache, block records,
+// the sharded SpMV's panel view.  Everything is rebuilt lazily by the next operator call.
+void invalidate_matrix(bmsp_matrix_s *m, int structure_changed)
+{
+    if (!m) return;
+    BMSP_HIP(hipDeviceSynchronize());  // no kernel may still be reading what is about to go back to the pool
+    pool_free(m->dense_tiles); m->dense_tiles = nullptr;
+    if (!structure_changed) return;
+    pool_free(m->rowptr); m->rowptr = nullptr; m->rowptr_rows = 0; m->max_row_blocks = -1;
+    pool_free(m->spmv_chunks); m->spmv_chunks = nullptr; m->spmv_num_chunks = 0; m->spmv_plan_long = 0; m->spmv_full_tiles = 0;
+    pool_free(m->spmv_pos); m->spmv_pos = nullptr; m->spmv_pos_base = 0; m->spmv_pos_count = 0; m->spmv_pos_tried = 0;
+    pool_free(m->block_meta); m->block_meta = nullptr;
+    free_matrix(m->shard_view); m->shard_view = nullptr; m->shard_world = 0; m->shard_rank = 0; m->shard_bounds.clear();
+}
+
 void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st)
 {
     if (m->rowptr) return;

@@ -325,6 +325,14 @@ int bmsp_matrix_free(bmsp_matrix_t m)
     BMSP_API_END
 }
 
+int bmsp_matrix_invalidate(bmsp_matrix_t m, int structure_changed)
+{
+    BMSP_API_BEGIN
+    need(m, "matrix");
+    invalidate_matrix(m, structure_changed);
+    BMSP_API_END
+}
+
 int bmsp_matrix_info(bmsp_matrix_t m, int *num_rows, int *num_cols, int64_t *nnz, int64_t *block_num, bmsp_dtype *dtype, int *transposed)
 {
     BMSP_API_BEGIN
@@ -475,6 +483,30 @@ int bmsp_comm_init(const void *id_bytes, int world, int rank, bmsp_comm_t *out)
     BMSP_API_BEGIN
     need(id_bytes, "id_bytes"); need(out, "out");
     *out = comm_init(id_bytes, world, rank);
+    BMSP_API_END
+}
+
+int bmsp_comm_init_loopback(int world, bmsp_comm_t *out)
+{
+    BMSP_API_BEGIN
+    need(out, "out");
+    *out = comm_init_loopback(world);
+    BMSP_API_END
+}
+
+int bmsp_shard_layout(int parts, const int64_t *block_nums, const int64_t *nnzs, int64_t *block_start, int64_t *value_start)
+{
+    BMSP_API_BEGIN
+    need(block_nums, "block_nums"); need(nnzs, "nnzs"); need(block_start, "block_start"); need(value_start, "value_start");
+    shard_layout(parts, block_nums, nnzs, block_start, value_start);
+    BMSP_API_END
+}
+
+int bmsp_shard_row_slices(int num_rows, int parts, const int64_t *bounds, int64_t *row_start, int64_t *row_count)
+{
+    BMSP_API_BEGIN
+    need(bounds, "bounds"); need(row_start, "row_start"); need(row_count, "row_count");
+    shard_row_slices(num_rows, parts, bounds, row_start, row_count);
     BMSP_API_END
 }
 

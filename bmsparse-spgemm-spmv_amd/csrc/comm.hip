@@ -10,8 +10,10 @@
 //     without a staging copy -- RCCL has no allgatherv, and panels balanced by WORK differ in SIZE by > 2x on skewed inputs.
 //     On the fully connected xGMI of an MI355X node the P concurrent broadcasts use all links at once.
 //   * offsets are re-based in place by an exclusive scan of the panels' value counts.
-// SpMV: block-row panels balanced by stored values, x replicated, every rank sweeps its panel straight into the full-length y and
-// the y slices are broadcast in place the same way.
+// SpMV: block-row panels balanced by stored values, x replicated, every rank's sweep writes ITS rows of the full-length y (and no
+// other row) and the y slices are broadcast in place the same way.
+// The exchange is split into layout (host arithmetic, shared) and transport (RCCL, or an in-process loopback that lets a one-GPU
+// box run every P > 1 branch): see "the exchange" below.
 //
 // librccl is NOT a link-time dependency of libbmsp.so: it is opened on the first bmsp_comm_* call (the copy already loaded in the
 // process -- e.g. PyTorch's -- if there is one, /opt/rocm/lib/librccl.so.1 otherwise), so single-GPU users never load it.
@@ -25,7 +27,10 @@
 #include <cstring>
 #include <memory>
 #include <thread>
+#include <sys/stat.h>
 #include <unistd.h>
+#include <array>
+#include <ctime>
 #include <vector>
 
 namespace bmsp {
@@ -88,21 +93,87 @@ struct AddU64 {
     __device__ void operator()(uint64_t i) const { p[i] += add; }
 };
 
-// every rank's `count[r]` elements of `elem` bytes land at dst + elem * start[r]; rank `me` sends `mine`
-void allgatherv_inplace(bmsp_comm_s *c, const void *mine, void *dst, const std::vector<int64_t> &count, const std::vector<int64_t> &start,
-                        size_t elem, hipStream_t st)
+// ---- the exchange: layout (shared by every transport) and the two transports ----------------------------------------------------------
+// A transport only moves bytes: `gather_sizes` makes every panel's (blocks, values) pair known on every rank, `slices` lands every
+// panel's `count[r]` elements at dst + elem * start[r].  Everything else -- the size gather's result -> slice starts (shard_layout) ->
+// allocation of the whole C -> offset re-basing (AddU64 for r > 0) -> terminal offset -- is the same code for both:
+//   * RCCL (one process per GPU): sizes by ncclAllGather, slices by ncclGroupStart .. P x ncclBroadcast(root = r) .. ncclGroupEnd;
+//   * loopback (ONE process, ONE device, any P): the P panel products are computed one after another on this device and a "broadcast"
+//     is a hipMemcpyAsync of the panel into its final slice.  It exists so that every P > 1 branch of the sharded operators runs on a
+//     one-GPU box (tests/test_gpu_parity.py: P in {2, 3, 8}, incl. an empty panel) -- what it does not cover is RCCL itself.
+// `src[r]` is the panel of rank r where this process holds it (RCCL: only r == rank; loopback: every r).
+void exchange_sizes(bmsp_comm_s *c, const std::vector<std::array<int64_t, 2>> &local, std::vector<int64_t> &sizes, hipStream_t st)
 {
+    const int P = c->world;
+    sizes.assign((size_t)2 * P, 0);
+    if (c->loopback) {
+        for (int r = 0; r < P; r++) { sizes[(size_t)2 * r] = local[(size_t)r][0]; sizes[(size_t)2 * r + 1] = local[(size_t)r][1]; }
+        return;
+    }
+    DevBuf<int64_t> d_sizes((size_t)2 * P), d_mine(2);
+    BMSP_HIP(hipMemcpyAsync(d_mine.p, local[(size_t)c->rank].data(), 16, hipMemcpyHostToDevice, st));
+    BMSP_NCCL(rccl().AllGather(d_mine.p, d_sizes.p, 2, ncclInt64, (ncclComm_t)c->comm, st));
+    BMSP_HIP(hipMemcpyAsync(sizes.data(), d_sizes.p, 8 * sizes.size(), hipMemcpyDeviceToHost, st));
+    BMSP_HIP(hipStreamSynchronize(st));
+}
+
+void exchange_slices(bmsp_comm_s *c, const std::vector<const void *> &src, void *dst, const int64_t *count, const int64_t *start, size_t elem,
+                     hipStream_t st)
+{
+    if (c->loopback) {
+        for (int r = 0; r < c->world; r++) {
+            if (count[r] == 0) continue;
+            char *slice = (char *)dst + elem * (size_t)start[r];
+            if ((const void *)slice != src[(size_t)r]) BMSP_HIP(hipMemcpyAsync(slice, src[(size_t)r], elem * (size_t)count[r], hipMemcpyDeviceToDevice, st));
+        }
+        return;
+    }
     Rccl &R = rccl();
     BMSP_NCCL(R.GroupStart());
     for (int r = 0; r < c->world; r++) {
-        if (count[(size_t)r] == 0) continue;
-        char *slice = (char *)dst + elem * (size_t)start[(size_t)r];
-        BMSP_NCCL(R.Broadcast(r == c->rank ? mine : (const void *)slice, slice, elem * (size_t)count[(size_t)r], ncclChar, r, (ncclComm_t)c->comm, st));
+        if (count[r] == 0) continue;
+        char *slice = (char *)dst + elem * (size_t)start[r];
+        BMSP_NCCL(R.Broadcast(r == c->rank ? src[(size_t)r] : (const void *)slice, slice, elem * (size_t)count[r], ncclChar, r, (ncclComm_t)c->comm, st));
     }
     BMSP_NCCL(R.GroupEnd());
 }
 
+// the panels this process computes: its own rank, or all of them in loopback
+std::vector<int> local_ranks(const bmsp_comm_s *c)
+{
+    std::vector<int> v;
+    if (c->loopback)
+        for (int r = 0; r < c->world; r++) v.push_back(r);
+    else
+        v.push_back(c->rank);
+    return v;
+}
+
 }  // namespace
+
+// slice layout of the exchanged C: panel r's blocks land at block_start[r], its values at value_start[r] (exclusive sums; entry
+// `parts` = the totals).  Host arithmetic only: exported as bmsp_shard_layout so that the world-size-2 CPU test drives THIS code.
+void shard_layout(int parts, const int64_t *block_nums, const int64_t *nnzs, int64_t *block_start, int64_t *value_start)
+{
+    if (parts < 1) fail(BMSP_ERR_INVALID, "parts must be >= 1");
+    block_start[0] = 0; value_start[0] = 0;
+    for (int r = 0; r < parts; r++) {
+        if (block_nums[r] < 0 || nnzs[r] < 0) fail(BMSP_ERR_INVALID, "negative panel size");
+        block_start[r + 1] = block_start[r] + block_nums[r];
+        value_start[r + 1] = value_start[r] + nnzs[r];
+    }
+}
+
+// row slices of the exchanged y: panel r = block-rows [bounds[r], bounds[r+1]) -> rows [row_start[r], row_start[r] + row_count[r])
+void shard_row_slices(int num_rows, int parts, const int64_t *bounds, int64_t *row_start, int64_t *row_count)
+{
+    if (parts < 1) fail(BMSP_ERR_INVALID, "parts must be >= 1");
+    for (int r = 0; r < parts; r++) {
+        if (bounds[r] < 0 || bounds[r + 1] < bounds[r]) fail(BMSP_ERR_INVALID, "panel bounds must ascend");
+        const int64_t r0 = std::min<int64_t>(bounds[r] * 8, num_rows), r1 = std::min<int64_t>(bounds[r + 1] * 8, num_rows);
+        row_start[r] = r0; row_count[r] = r1 - r0;
+    }
+}
 
 void comm_unique_id(void *id128)
 {
@@ -126,41 +197,71 @@ bmsp_comm_s *comm_init(const void *id128, int world, int rank)
     return c.release();
 }
 
+bmsp_comm_s *comm_init_loopback(int world)
+{
+    if (world < 1) fail(BMSP_ERR_INVALID, "world must be >= 1");
+    bmsp_comm_s *c = new bmsp_comm_s();
+    c->world = world; c->rank = 0; c->loopback = 1;
+    BMSP_HIP(hipGetDevice(&c->device));
+    return c;
+}
+
 // BMSP_WORLD / BMSP_RANK / BMSP_COMM_FILE: the rendezvous of the drop-in executables (one process per GPU, started by any
-// launcher): rank 0 writes the 128-byte id to the file (tmp + rename), the others wait for it
+// launcher).  Rank 0 removes whatever a crashed run left at the path, then publishes {magic, nonce, 128-byte id} (tmp + rename);
+// the others wait for a file that carries the magic, THEIR nonce (BMSP_COMM_NONCE, a number the launcher gives every rank of one
+// run; 0 when unset) and -- when no nonce is set -- is not older than 120 s before this process looked first (a file left by an
+// earlier run is then refused instead of being joined: its id is dead and ncclCommInitRank would block on it).
+namespace {
+struct Rendezvous {
+    char magic[8];
+    uint64_t nonce;
+    char id[128];
+};
+const char kRdvMagic[8] = {'B', 'M', 'S', 'P', 'c', 'o', 'm', '1'};
+}  // namespace
+
 bmsp_comm_s *comm_init_from_env()
 {
-    const char *w = getenv("BMSP_WORLD"), *r = getenv("BMSP_RANK"), *f = getenv("BMSP_COMM_FILE");
+    const char *w = getenv("BMSP_WORLD"), *r = getenv("BMSP_RANK"), *f = getenv("BMSP_COMM_FILE"), *ne = getenv("BMSP_COMM_NONCE");
     if (!w || !r) fail(BMSP_ERR_INVALID, "BMSP_WORLD and BMSP_RANK must be set");
     const int world = atoi(w), rank = atoi(r);
     if (world < 1 || rank < 0 || rank >= world) fail(BMSP_ERR_INVALID, "BMSP_RANK %d outside BMSP_WORLD %d", rank, world);
-    char id[128];
+    Rendezvous rv{};
     if (world == 1) {
-        comm_unique_id(id);
-        return comm_init(id, 1, 0);
+        comm_unique_id(rv.id);
+        return comm_init(rv.id, 1, 0);
     }
     if (!f) fail(BMSP_ERR_INVALID, "BMSP_COMM_FILE (a path every rank can reach) must be set when BMSP_WORLD > 1");
+    const uint64_t nonce = ne ? strtoull(ne, nullptr, 0) : 0ull;
     const std::string path = f, tmp = path + ".tmp";
     if (rank == 0) {
-        comm_unique_id(id);
+        (void)unlink(path.c_str());  // a leftover of a crashed run must never be read as this run's id
+        memcpy(rv.magic, kRdvMagic, 8);
+        rv.nonce = nonce;
+        comm_unique_id(rv.id);
         FILE *fp = fopen(tmp.c_str(), "wb");
-        if (!fp || fwrite(id, 1, sizeof id, fp) != sizeof id) fail(BMSP_ERR_IO, "cannot write %s", tmp.c_str());
+        if (!fp || fwrite(&rv, 1, sizeof rv, fp) != sizeof rv) fail(BMSP_ERR_IO, "cannot write %s", tmp.c_str());
         fclose(fp);
         if (rename(tmp.c_str(), path.c_str()) != 0) fail(BMSP_ERR_IO, "cannot publish %s", path.c_str());
     } else {
         const auto t0 = std::chrono::steady_clock::now();
+        const time_t first_look = time(nullptr);
         for (;;) {
             FILE *fp = fopen(path.c_str(), "rb");
             if (fp) {
-                const size_t n = fread(id, 1, sizeof id, fp);
+                const size_t n = fread(&rv, 1, sizeof rv, fp);
+                struct stat sb{};
+                const bool have_stat = fstat(fileno(fp), &sb) == 0;
                 fclose(fp);
-                if (n == sizeof id) break;
+                const bool fresh = ne != nullptr || !have_stat || sb.st_mtime + 120 >= first_look;
+                if (n == sizeof rv && memcmp(rv.magic, kRdvMagic, 8) == 0 && rv.nonce == nonce && fresh) break;
             }
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) fail(BMSP_ERR_IO, "timed out waiting for %s", path.c_str());
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                fail(BMSP_ERR_IO, "timed out waiting for a rendezvous file of this run at %s (stale or foreign files are refused)", path.c_str());
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
     }
-    bmsp_comm_s *c = comm_init(id, world, rank);
+    bmsp_comm_s *c = comm_init(rv.id, world, rank);
     if (rank == 0) (void)unlink(path.c_str());  // every rank has read it: the collective init above has completed
     return c;
 }
@@ -179,47 +280,55 @@ void spgemm_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_mat
     const int P = c->world;
     std::vector<int64_t> bounds((size_t)P + 1);
     partition_rows(A, B, P, bounds.data(), st, nullptr);
-    // this rank's panel product
-    std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> view(row_panel(A, bounds[(size_t)c->rank], bounds[(size_t)c->rank + 1], st), free_matrix);
-    bmsp_matrix_s *cp_raw = nullptr;
-    bmsp_spgemm_stats ps{};
-    try {
-        spgemm(view.get(), B, &cp_raw, mode, tc_version, verbose, st, &ps);
-    } catch (const TaskRangeExceeded &) {  // a panel beyond one task list: run it in sub-panels (same answer)
-        spgemm_paneled(view.get(), B, &cp_raw, mode, tc_version, verbose, st, &ps);
+    // the panel products this process owns (its rank's; all P, one after another, in loopback)
+    typedef std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> MatPtr;
+    std::vector<MatPtr> cp;
+    for (int r = 0; r < P; r++) cp.emplace_back(nullptr, free_matrix);
+    std::vector<std::array<int64_t, 2>> local((size_t)P, std::array<int64_t, 2>{0, 0});
+    bmsp_spgemm_stats ps{};  // this rank's panel (loopback: summed over the panels, like the paneled single-GPU product)
+    for (int r : local_ranks(c)) {
+        MatPtr view(row_panel(A, bounds[(size_t)r], bounds[(size_t)r + 1], st), free_matrix);
+        bmsp_matrix_s *cp_raw = nullptr;
+        bmsp_spgemm_stats one{};
+        try {
+            spgemm(view.get(), B, &cp_raw, mode, tc_version, verbose, st, &one);
+        } catch (const TaskRangeExceeded &) {  // a panel beyond one task list: run it in sub-panels (same answer)
+            spgemm_paneled(view.get(), B, &cp_raw, mode, tc_version, verbose, st, &one);
+        }
+        cp[(size_t)r].reset(cp_raw);
+        local[(size_t)r] = {cp_raw->block_num, cp_raw->nnz};
+        ps.task_list_size += one.task_list_size; ps.bmp_reduction += one.bmp_reduction; ps.surviving_tasks += one.surviving_tasks;
+        ps.c_blocks += one.c_blocks; ps.c_nnz += one.c_nnz;
+        for (int i = 0; i < 10; i++) ps.t_us[i] += one.t_us[i];
+        ps.sort_path = one.sort_path; ps.mac_kernel = one.mac_kernel;
     }
-    std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> cp(cp_raw, free_matrix);
+    const bmsp_dtype cdt = A->dtype == BMSP_F64 ? BMSP_F64 : BMSP_F32;
     StageTimer tm(st, true);
     tm.mark(-1);
-    // sizes of every panel
-    DevBuf<int64_t> d_sizes((size_t)2 * P);
-    int64_t mine[2] = {cp->block_num, cp->nnz};
-    DevBuf<int64_t> d_mine(2);
-    BMSP_HIP(hipMemcpyAsync(d_mine.p, mine, sizeof mine, hipMemcpyHostToDevice, st));
-    BMSP_NCCL(rccl().AllGather(d_mine.p, d_sizes.p, 2, ncclInt64, (ncclComm_t)c->comm, st));
-    std::vector<int64_t> sizes((size_t)2 * P);
-    BMSP_HIP(hipMemcpyAsync(sizes.data(), d_sizes.p, 8 * sizes.size(), hipMemcpyDeviceToHost, st));
-    BMSP_HIP(hipStreamSynchronize(st));
+    // sizes of every panel -> where every panel lands
+    std::vector<int64_t> sizes;
+    exchange_sizes(c, local, sizes, st);
     std::vector<int64_t> nb((size_t)P), nz((size_t)P), b0((size_t)P + 1, 0), z0((size_t)P + 1, 0);
-    for (int r = 0; r < P; r++) {
-        nb[(size_t)r] = sizes[(size_t)2 * r]; nz[(size_t)r] = sizes[(size_t)2 * r + 1];
-        b0[(size_t)r + 1] = b0[(size_t)r] + nb[(size_t)r];
-        z0[(size_t)r + 1] = z0[(size_t)r] + nz[(size_t)r];
-    }
+    for (int r = 0; r < P; r++) { nb[(size_t)r] = sizes[(size_t)2 * r]; nz[(size_t)r] = sizes[(size_t)2 * r + 1]; }
+    shard_layout(P, nb.data(), nz.data(), b0.data(), z0.data());
     const int64_t NB = b0[(size_t)P], NZ = z0[(size_t)P];
-    // the whole C at its final size; every panel is broadcast into its slice
-    std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> C(new bmsp_matrix_s(), free_matrix);
-    C->num_rows = A->num_rows; C->num_cols = B->num_cols; C->dtype = cp->dtype; C->transposed = 0;
+    // the whole C at its final size; every panel travels straight into its slice
+    MatPtr C(new bmsp_matrix_s(), free_matrix);
+    C->num_rows = A->num_rows; C->num_cols = B->num_cols; C->dtype = cdt; C->transposed = 0;
     C->block_num = NB; C->nnz = NZ;
     const size_t es = dtype_size(C->dtype);
     C->keys = (uint64_t *)pool_alloc(8 * (size_t)(NB ? NB : 1));
     C->bmps = (uint64_t *)pool_alloc(8 * (size_t)(NB ? NB : 1));
     C->offsets = (uint64_t *)pool_alloc(8 * ((size_t)NB + 1));
     C->values = pool_alloc(es * (size_t)(NZ ? NZ : 1));
-    allgatherv_inplace(c, cp->keys, C->keys, nb, b0, 8, st);
-    allgatherv_inplace(c, cp->bmps, C->bmps, nb, b0, 8, st);
-    allgatherv_inplace(c, cp->offsets, C->offsets, nb, b0, 8, st);  // block_num entries per panel (the terminal one is rebuilt)
-    allgatherv_inplace(c, cp->values, C->values, nz, z0, es, st);
+    std::vector<const void *> sk((size_t)P, nullptr), sb((size_t)P, nullptr), so((size_t)P, nullptr), sv((size_t)P, nullptr);
+    for (int r = 0; r < P; r++)
+        if (cp[(size_t)r]) { sk[(size_t)r] = cp[(size_t)r]->keys; sb[(size_t)r] = cp[(size_t)r]->bmps; so[(size_t)r] = cp[(size_t)r]->offsets; sv[(size_t)r] = cp[(size_t)r]->values; }
+    exchange_slices(c, sk, C->keys, nb.data(), b0.data(), 8, st);
+    exchange_slices(c, sb, C->bmps, nb.data(), b0.data(), 8, st);
+    exchange_slices(c, so, C->offsets, nb.data(), b0.data(), 8, st);  // block_num entries per panel (the terminal one is rebuilt)
+    exchange_slices(c, sv, C->values, nz.data(), z0.data(), es, st);
+    // a panel's offsets count from its own first value: re-base by the values in front of it
     for (int r = 0; r < P; r++)
         if (nb[(size_t)r] && z0[(size_t)r]) device_for_each(AddU64{C->offsets + b0[(size_t)r], (uint64_t)z0[(size_t)r]}, (uint64_t)nb[(size_t)r], st);
     const uint64_t term = (uint64_t)NZ;
@@ -264,6 +373,7 @@ void spmv_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, const void *x, void *y, int 
 {
     if (!c || !A) fail(BMSP_ERR_INVALID, "null argument");
     const int P = c->world;
+    const size_t es = A->dtype == BMSP_F64 ? 8 : 4;
     // the panel view (with its cached sweep plan) is kept on the matrix for repeated products with the same communicator shape
     if (!A->shard_view || A->shard_world != P || A->shard_rank != c->rank) {
         free_matrix(A->shard_view);
@@ -274,19 +384,33 @@ void spmv_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, const void *x, void *y, int 
         A->shard_view = row_panel(A, bounds[(size_t)c->rank], bounds[(size_t)c->rank + 1], st);
         A->shard_world = P; A->shard_rank = c->rank;
     }
-    spmv(A->shard_view, x, y, variant, st);  // writes the whole y: zeros outside the panel
+    std::vector<int64_t> cnt((size_t)P), start((size_t)P);
+    shard_row_slices(A->num_rows, P, A->shard_bounds.data(), start.data(), cnt.data());
+    int64_t bytes = 0;
+    for (int r = 0; r < P; r++) bytes += cnt[(size_t)r] * (int64_t)es;
+    // every panel's sweep writes ITS rows of u and nothing else (rows outside the panel are another rank's to deliver)
+    std::vector<const void *> src((size_t)P, nullptr);
+    std::vector<DevBuf<char>> scratch;  // loopback: the other "ranks'" result vectors (poisoned, so a row nobody delivers shows)
+    if (c->loopback) {
+        scratch.resize((size_t)P);
+        for (int r = 0; r < P; r++) {
+            std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> view(row_panel(A, A->shard_bounds[(size_t)r], A->shard_bounds[(size_t)r + 1], st), free_matrix);
+            scratch[(size_t)r].alloc(es * (size_t)std::max(1, A->num_rows));
+            BMSP_HIP(hipMemsetAsync(scratch[(size_t)r].p, 0xff, es * (size_t)A->num_rows, st));
+            spmv(view.get(), x, scratch[(size_t)r].p, variant, st, start[(size_t)r], start[(size_t)r] + cnt[(size_t)r]);
+            BMSP_HIP(hipStreamSynchronize(st));  // the view (and its plan) goes away below
+            src[(size_t)r] = scratch[(size_t)r].p + es * (size_t)start[(size_t)r];
+        }
+    } else {
+        const int r = c->rank;
+        spmv(A->shard_view, x, y, variant, st, start[(size_t)r], start[(size_t)r] + cnt[(size_t)r]);
+        src[(size_t)r] = (const char *)y + es * (size_t)start[(size_t)r];
+    }
     StageTimer tm(st, sh != nullptr);
     tm.mark(-1);
-    const size_t es = A->dtype == BMSP_F64 ? 8 : 4;
-    std::vector<int64_t> cnt((size_t)P), start((size_t)P);
-    int64_t bytes = 0;
-    for (int r = 0; r < P; r++) {
-        const int64_t r0 = std::min<int64_t>(A->shard_bounds[(size_t)r] * 8, A->num_rows), r1 = std::min<int64_t>(A->shard_bounds[(size_t)r + 1] * 8, A->num_rows);
-        start[(size_t)r] = r0; cnt[(size_t)r] = r1 - r0;
-        bytes += (r1 - r0) * (int64_t)es;
-    }
-    allgatherv_inplace(c, (const char *)y + es * (size_t)start[(size_t)c->rank], y, cnt, start, es, st);
+    exchange_slices(c, src, y, cnt.data(), start.data(), es, st);
     tm.mark(0);
+    if (c->loopback) BMSP_HIP(hipStreamSynchronize(st));  // scratch vectors are released on return
     if (sh) {
         BMSP_HIP(hipStreamSynchronize(st));
         double t_us[10] = {0};

@@ -53,6 +53,7 @@ struct bmsp_matrix_s {
 struct bmsp_comm_s {
     void *comm = nullptr;
     int rank = 0, world = 1, device = 0;
+    int loopback = 0;  // 1: no RCCL -- every panel is computed by this process on this device, "broadcast" = device copy (comm.hip)
 };
 
 namespace bmsp {
@@ -95,7 +96,7 @@ void free_matrix(bmsp_matrix_s *m);
 void prepare_spmv(bmsp_matrix_s *m, hipStream_t st);
 void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st);
 
-void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st);
+void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st, int64_t row_lo = 0, int64_t row_hi = -1);
 void spmm(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, int k, hipStream_t st);
 void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int tc_version, int verbose, hipStream_t st,
             bmsp_spgemm_stats *stats);
@@ -112,6 +113,10 @@ void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const
 void comm_unique_id(void *id128);
 bmsp_comm_s *comm_init(const void *id128, int world, int rank);
 bmsp_comm_s *comm_init_from_env();
+bmsp_comm_s *comm_init_loopback(int world);
+void shard_layout(int parts, const int64_t *block_nums, const int64_t *nnzs, int64_t *block_start, int64_t *value_start);
+void shard_row_slices(int num_rows, int parts, const int64_t *bounds, int64_t *row_start, int64_t *row_count);
+void invalidate_matrix(bmsp_matrix_s *m, int structure_changed);
 void comm_free(bmsp_comm_s *c);
 void spgemm_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int tc_version, int verbose, hipStream_t st,
                     bmsp_spgemm_stats *stats, bmsp_shard_stats *sh);

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, 8
                                                               const uint64_t *__restrict__ offsets, const T *__restrict__ values,
                                                               const T *__restrict__ x, typename Acc<T>::type *__restrict__ y,
                                                               typename Acc<T>::type *__restrict__ carry, uint32_t *__restrict__ counters,
-                                                              uint32_t num_rows, uint32_t num_cols, uint32_t values_bytes)
+                                                              uint32_t num_rows, uint32_t num_cols, uint32_t values_bytes, uint32_t row_lo)
 {
     using A = typename Acc<T>::type;
     __shared__ A tile_all[4][kItemRows * 8];
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, 8
         // short item: the wave owns u[row_begin*8, row_end*8)
         const uint32_t n_out = (it.row_end - it.row_begin) * 8u, out0 = it.row_begin * 8u;
         for (uint32_t e = lane; e < n_out; e += 64)
-            if (out0 + e < num_rows) y[out0 + e] = tile[e];
+            if (out0 + e >= row_lo && out0 + e < num_rows) y[out0 + e] = tile[e];
         __builtin_amdgcn_wave_barrier();
         continue;
     }
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, 8
 #pragma unroll
     for (int d = 8; d < 64; d <<= 1) sum += __shfl_xor(sum, d, kWave);
     const uint32_t row = it.row_begin * 8u + (uint32_t)r;
-    if (g == 0 && row < num_rows) y[row] = sum;
+    if (g == 0 && row >= row_lo && row < num_rows) y[row] = sum;
     if (lane == 0) __hip_atomic_store(&counters[it.long_idx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
                                                           const T *__restrict__ x, typename Acc<T>::type *__restrict__ y,
                                                           typename Acc<T>::type *__restrict__ carry, uint32_t *__restrict__ counters,
                                                           uint32_t num_rows, uint32_t num_cols, uint32_t values_bytes,
-                                                          uint16_t *__restrict__ pos, uint32_t pos_base, uint32_t pos_count)
+                                                          uint16_t *__restrict__ pos, uint32_t pos_base, uint32_t pos_count, uint32_t row_lo)
 {
     using A = typename Acc<T>::type;
     using L = VsLds<A, MODE, RED>;
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
                 // short item: the wave owns u[row_begin*8, row_end*8)
                 const uint32_t n_out = (it.row_end - it.row_begin) * 8u, out0 = it.row_begin * 8u;
                 for (uint32_t e = lane; e < n_out; e += 64)
-                    if (out0 + e < num_rows) y[out0 + e] = tile[e];
+                    if (out0 + e >= row_lo && out0 + e < num_rows) y[out0 + e] = tile[e];
             } else {
                 // long row: park the partial sums, the last arriver folds them (same protocol as spmv_sweep_kernel)
                 A mine = lane < 8 ? tile[lane & 7] : A(0);
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
 #pragma unroll
                     for (int d = 8; d < 64; d <<= 1) sum += __shfl_xor(sum, d, kWave);
                     const uint32_t row = it.row_begin * 8u + (uint32_t)r;
-                    if (g == 0 && row < num_rows) y[row] = sum;
+                    if (g == 0 && row >= row_lo && row < num_rows) y[row] = sum;
                     if (lane == 0) __hip_atomic_store(&counters[it.long_idx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -884,7 +884,7 @@ void build_pos_cache(bmsp_matrix_s *A, hipStream_t st)
     const uint32_t n_items = (uint32_t)A->spmv_num_chunks;
     hipLaunchKernelGGL((spmv_vstream_kernel<float, kBuild, kAtomic>), dim3(n_items), dim3(64), 0, st, (const SweepItem *)(mem + 64), n_items, A->keys,
                        A->bmps, A->offsets, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr,
-                       (uint32_t)A->num_rows, (uint32_t)A->num_cols, 0u, pos, (uint32_t)base, (uint32_t)count);
+                       (uint32_t)A->num_rows, (uint32_t)A->num_cols, 0u, pos, (uint32_t)base, (uint32_t)count, 0u);
     BMSP_CHECK_LAUNCH();
     A->spmv_pos = pos;
     A->spmv_pos_base = (int64_t)base;
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(kThreads) void spmv_blockrow_kernel(const uint32_t 
                                                                  const uint64_t *__restrict__ bmps, const uint64_t *__restrict__ offsets,
                                                                  const T *__restrict__ values, const T *__restrict__ x,
                                                                  typename Acc<T>::type *__restrict__ y, uint32_t num_rows,
-                                                                 uint32_t num_cols, uint32_t num_block_rows)
+                                                                 uint32_t num_cols, uint32_t num_block_rows, uint32_t row_lo)
 {
     using A = typename Acc<T>::type;
     constexpr int GROUPS = LANES_PER_ROW / 8;  // tiles in flight per block-row per step
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(kThreads) void spmv_blockrow_kernel(const uint32_t 
         for (int d = 8; d < LANES_PER_ROW; d <<= 1) acc += __shfl_xor(acc, d, kWave);
     }
     uint32_t row = gid * 8u + (uint32_t)r;
-    if (g == 0 && row < num_rows) y[row] = acc;
+    if (g == 0 && row >= row_lo && row < num_rows) y[row] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowgroup_kernel(const uint32_t 
                                                                  const uint64_t *__restrict__ bmps, const uint64_t *__restrict__ offsets,
                                                                  const T *__restrict__ values, const T *__restrict__ x,
                                                                  typename Acc<T>::type *__restrict__ y, uint32_t num_rows, uint32_t num_cols,
-                                                                 uint32_t nbr, uint32_t values_bytes, uint32_t passes)
+                                                                 uint32_t nbr, uint32_t values_bytes, uint32_t passes, uint32_t row_lo)
 {
     using A = typename Acc<T>::type;
     const int lane = lane_id(), j = lane & 15, g = lane >> 4;
@@ -1048,29 +1048,29 @@ __global__ __launch_bounds__(kThreads) void spmv_rowgroup_kernel(const uint32_t 
         if (sizeof(A) == 4) acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)acc), 0xB1, 0xf, 0xf, false));  // quad_perm 1,0,3,2
         else acc += __shfl_xor(acc, 1, kWave);
         const uint32_t row = br * 8u + (uint32_t)(j >> 1);
-        if (valid && !(j & 1) && row < num_rows) y[row] = acc;
+        if (valid && !(j & 1) && row >= row_lo && row < num_rows) y[row] = acc;
     }
 }
 
 template <typename T>
-void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st)
+void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st, uint32_t row_lo, uint32_t row_hi)
 {
     using Ac = typename Acc<T>::type;
     uint32_t nbr = (uint32_t)A->num_block_rows();
     if (nbr == 0) return;
     if (variant == BMSP_SPMV_BATCHED) {
         hipLaunchKernelGGL((spmv_blockrow_kernel<T, 64>), dim3((nbr + 3) / 4), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps,
-                           A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows,
-                           (uint32_t)A->num_cols, nbr);
+                           A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, row_hi,
+                           (uint32_t)A->num_cols, nbr, row_lo);
     } else if (variant == 2) {
         hipLaunchKernelGGL((spmv_blockrow_kernel<T, 8>), dim3((nbr + 31) / 32), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps,
-                           A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows,
-                           (uint32_t)A->num_cols, nbr);
+                           A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, row_hi,
+                           (uint32_t)A->num_cols, nbr, row_lo);
     } else if ((size_t)A->values_extent() * sizeof(T) >= (1ull << 32) || (size_t)A->num_cols * sizeof(T) >= (1ull << 32)) {
         // buffer descriptors address 4 GiB; beyond that fall back to the pointer-based block-row kernel
         hipLaunchKernelGGL((spmv_blockrow_kernel<T, 64>), dim3((nbr + 3) / 4), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps,
-                           A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows,
-                           (uint32_t)A->num_cols, nbr);
+                           A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, row_hi,
+                           (uint32_t)A->num_cols, nbr, row_lo);
     } else {
         build_plan(A, st);
         // dense tiles and no hub block-row: the row-group kernel streams the value array with 16-byte loads (variant 3); the 16-byte
@@ -1083,8 +1083,8 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
             const uint32_t passes = pe ? (uint32_t)std::max(1, atoi(pe)) : (groups > 32768 ? 2u : 1u);
             const uint32_t waves = (groups + passes - 1) / passes;
             hipLaunchKernelGGL((spmv_rowgroup_kernel<T, U>), dim3((waves + 3) / 4), dim3(kThreads), 0, st, A->rowptr, A->keys, A->bmps, A->offsets,
-                               (const T *)A->values, (const T *)v, (Ac *)u, (uint32_t)A->num_rows, (uint32_t)A->num_cols, nbr,
-                               (uint32_t)((size_t)A->values_extent() * sizeof(T)) + 16u, passes);
+                               (const T *)A->values, (const T *)v, (Ac *)u, row_hi, (uint32_t)A->num_cols, nbr,
+                               (uint32_t)((size_t)A->values_extent() * sizeof(T)) + 16u, passes, row_lo);
             BMSP_CHECK_LAUNCH();
             return;
         }
@@ -1098,8 +1098,8 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
 #define BMSP_VS_LAUNCH(MODE, RED)                                                                                                                \
     hipLaunchKernelGGL((spmv_vstream_kernel<T, MODE, RED>), dim3(n_items), dim3(64), 0, st, (const SweepItem *)(mem + 64), n_items, A->keys, A->bmps, \
                        A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (Ac *)(mem + A->spmv_plan_off_carry),                             \
-                       (uint32_t *)(mem + A->spmv_plan_off_cnt), (uint32_t)A->num_rows, (uint32_t)A->num_cols,                                    \
-                       (uint32_t)((size_t)A->values_extent() * sizeof(T)), A->spmv_pos, (uint32_t)A->spmv_pos_base, (uint32_t)A->spmv_pos_count)
+                       (uint32_t *)(mem + A->spmv_plan_off_cnt), row_hi, (uint32_t)A->num_cols,                                                    \
+                       (uint32_t)((size_t)A->values_extent() * sizeof(T)), A->spmv_pos, (uint32_t)A->spmv_pos_base, (uint32_t)A->spmv_pos_count, row_lo)
             if (cached && red == kAtomic) BMSP_VS_LAUNCH(kCached, kAtomic);
             else if (cached) BMSP_VS_LAUNCH(kCached, kSorted);
             else if (red == kAtomic) BMSP_VS_LAUNCH(kDecode, kAtomic);
@@ -1116,8 +1116,8 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
         const uint32_t grid = pers ? std::min<uint32_t>((n_items + 3) / 4, (uint32_t)atoi(pers)) : (n_items + 3) / 4;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, st, (const SweepItem *)(mem + 64), n_items,
                            A->keys, A->bmps, A->offsets, (const T *)A->values, (const T *)v, (Ac *)u,
-                           (Ac *)(mem + A->spmv_plan_off_carry), (uint32_t *)(mem + A->spmv_plan_off_cnt), (uint32_t)A->num_rows,
-                           (uint32_t)A->num_cols, (uint32_t)((size_t)A->values_extent() * sizeof(T)));
+                           (Ac *)(mem + A->spmv_plan_off_carry), (uint32_t *)(mem + A->spmv_plan_off_cnt), row_hi,
+                           (uint32_t)A->num_cols, (uint32_t)((size_t)A->values_extent() * sizeof(T)), row_lo);
     }
     BMSP_CHECK_LAUNCH();
 }
@@ -1134,16 +1134,20 @@ void prepare_spmv(bmsp_matrix_s *A, hipStream_t st)
     if (vstream_eligible(A) && !rowgroup) build_pos_cache(A, st);
 }
 
-void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st)
+// row_lo / row_hi: only rows [row_lo, row_hi) of u are written (the sharded sweep: a rank writes its own slice and nothing else);
+// the default is every row
+void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st, int64_t row_lo, int64_t row_hi)
 {
     if (A->transposed) fail(BMSP_ERR_INVALID, "SpMV needs a matrix built with transposed=0");
     if (!v || !u) fail(BMSP_ERR_INVALID, "null vector");
     if (variant < 0 || variant > 3) fail(BMSP_ERR_INVALID, "unknown SpMV variant %d", variant);
     ensure_rowptr(A, st);
+    const uint32_t lo = (uint32_t)std::max<int64_t>(0, row_lo);
+    const uint32_t hi = (uint32_t)(row_hi < 0 ? (int64_t)A->num_rows : std::min<int64_t>(row_hi, A->num_rows));
     switch (A->dtype) {
-    case BMSP_F32: launch<float>(A, v, u, variant, st); break;
-    case BMSP_F16: launch<_Float16>(A, v, u, variant, st); break;
-    case BMSP_F64: launch<double>(A, v, u, variant, st); break;
+    case BMSP_F32: launch<float>(A, v, u, variant, st, lo, hi); break;
+    case BMSP_F16: launch<_Float16>(A, v, u, variant, st, lo, hi); break;
+    case BMSP_F64: launch<double>(A, v, u, variant, st, lo, hi); break;
     }
 }
 

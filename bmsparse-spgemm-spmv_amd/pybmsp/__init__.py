@@ -26,10 +26,10 @@ SYMBOLS = [
     "bmsp_memcpy_h2d", "bmsp_memcpy_d2h", "bmsp_memcpy_d2d", "bmsp_memset", "bmsp_synchronize", "bmsp_trim_pool",
     "bmsp_event_create", "bmsp_event_record", "bmsp_event_elapsed_ms", "bmsp_event_destroy",
     "bmsp_matrix_from_mtx", "bmsp_matrix_from_coo", "bmsp_matrix_from_coo_device", "bmsp_matrix_from_arrays",
-    "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_prepare", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
+    "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_prepare", "bmsp_matrix_invalidate", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
     "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmm", "bmsp_spgemm", "bmsp_selftest_mfma_layout", "bmsp_segsort_u64",
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
-    "bmsp_comm_unique_id", "bmsp_comm_init", "bmsp_comm_init_from_env", "bmsp_comm_info", "bmsp_comm_free", "bmsp_spgemm_sharded", "bmsp_spmv_sharded",
+    "bmsp_comm_unique_id", "bmsp_comm_init", "bmsp_comm_init_from_env", "bmsp_comm_init_loopback", "bmsp_shard_layout", "bmsp_shard_row_slices", "bmsp_comm_info", "bmsp_comm_free", "bmsp_spgemm_sharded", "bmsp_spmv_sharded",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
     "bmsp_csr_spmv", "bmsp_csr_multiply_host", "bmsp_csr_spmv_host", "bmsp_csr_free",
 ]
@@ -117,6 +117,10 @@ def lib():
         L.bmsp_comm_unique_id.argtypes = [vp]
         L.bmsp_comm_init.argtypes = [vp, i, i, p(vp)]
         L.bmsp_comm_init_from_env.argtypes = [p(vp)]
+        L.bmsp_comm_init_loopback.argtypes = [i, p(vp)]
+        L.bmsp_shard_layout.argtypes = [i, vp, vp, vp, vp]
+        L.bmsp_shard_row_slices.argtypes = [i, i, vp, vp, vp]
+        L.bmsp_matrix_invalidate.argtypes = [vp, i]
         L.bmsp_comm_info.argtypes = [vp, p(i), p(i)]
         L.bmsp_comm_free.argtypes = [vp]
         L.bmsp_spgemm_sharded.argtypes = [vp, vp, vp, p(vp), i, i, i, vp, p(SpgemmStats), p(ShardStats)]
@@ -275,6 +279,11 @@ class BmSpMatrix:
     def prepare(self, what=3, stream=None):
         """builds the cached sweep plan (1) / block-MAC operand records (2) ahead of the first product."""
         check(lib().bmsp_matrix_prepare(self.h, int(what), stream))
+        return self
+
+    def invalidate(self, structure_changed=False):
+        """after writing the arrays in place: drops the cached derived structures (bmsp_matrix_invalidate)."""
+        check(lib().bmsp_matrix_invalidate(self.h, int(bool(structure_changed))))
         return self
 
     def clone(self):
@@ -450,6 +459,15 @@ class Comm:
         check(lib().bmsp_comm_init(buf, int(world), int(rank), C.byref(h)))
         self.h, self.world, self.rank = h.value, int(world), int(rank)
 
+    @classmethod
+    def loopback(cls, world):
+        """`world` panels computed one after another on the current device, panels moved by device copies (no RCCL)."""
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        check(lib().bmsp_comm_init_loopback(int(world), C.byref(h)))
+        self.h, self.world, self.rank = h.value, int(world), 0
+        return self
+
     @staticmethod
     def unique_id():
         buf = C.create_string_buffer(128)
@@ -490,6 +508,23 @@ def spmv_sharded(comm, A, v, u=None, variant=0, stream=None):
     sh = ShardStats()
     check(lib().bmsp_spmv_sharded(comm.h, A.h, v.ptr, u.ptr, int(variant), stream, C.byref(sh)))
     return u, sh.as_dict()
+
+
+def shard_layout(block_nums, nnzs):
+    """(block_start, value_start), parts+1 entries each: where every panel of a sharded product lands (host arithmetic of comm.hip)."""
+    bn = np.ascontiguousarray(block_nums, dtype=np.int64)
+    nz = np.ascontiguousarray(nnzs, dtype=np.int64)
+    b0, z0 = np.zeros(bn.size + 1, np.int64), np.zeros(bn.size + 1, np.int64)
+    check(lib().bmsp_shard_layout(int(bn.size), bn.ctypes.data, nz.ctypes.data, b0.ctypes.data, z0.ctypes.data))
+    return b0, z0
+
+
+def shard_row_slices(num_rows, bounds):
+    """(row_start, row_count) per panel of a sharded SpMV with block-row bounds `bounds` (parts+1 entries)."""
+    b = np.ascontiguousarray(bounds, dtype=np.int64)
+    rs, rc = np.zeros(b.size - 1, np.int64), np.zeros(b.size - 1, np.int64)
+    check(lib().bmsp_shard_row_slices(int(num_rows), int(b.size - 1), b.ctypes.data, rs.ctypes.data, rc.ctypes.data))
+    return rs, rc
 
 
 class CSRMatrix:
@@ -533,15 +568,20 @@ class CSRMatrix:
         check(lib().bmsp_csr_multiply_host(self.h, other.h, C.byref(h), int(threads)))
         return CSRMatrix(h.value)
 
+    def shape(self):
+        nr, nc, nnz = C.c_int(), C.c_int(), C.c_int64()
+        check(lib().bmsp_csr_info(self.h, C.byref(nr), C.byref(nc), C.byref(nnz)))
+        return nr.value, nc.value, nnz.value
+
     def spmv_host(self, x, threads=0):
-        nr = self.arrays()[0]
+        nr = self.shape()[0]
         x = np.ascontiguousarray(x, dtype=np.float32)
         y = np.empty(nr, dtype=np.float32)
         check(lib().bmsp_csr_spmv_host(self.h, x.ctypes.data, y.ctypes.data, int(threads)))
         return y
 
     def spmv(self, x):
-        nr = self.arrays()[0]
+        nr = self.shape()[0]
         x = np.ascontiguousarray(x, dtype=np.float32)
         y = np.empty(nr, dtype=np.float32)
         check(lib().bmsp_csr_spmv(self.h, x.ctypes.data, y.ctypes.data))

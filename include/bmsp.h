@@ -110,6 +110,12 @@ int bmsp_matrix_info(bmsp_matrix_t m, int *num_rows, int *num_cols, int64_t *nnz
  * (src/bmSpMatrix.cu:194) and block_num+1 after a product (src/bmSparse_SPGEMM.cu:1087,1179). */
 int bmsp_matrix_arrays(bmsp_matrix_t m, uint64_t **d_keys, uint64_t **d_bmps, uint64_t **d_offsets,
                        void **d_values);
+/* The arrays above are writable (bmSpMatrix<T>::values.data() is public in the reference, include/bmSpMatrix.h:31, and the reference
+ * keeps no derived state, so it always sees current values).  This engine caches derived structures on the handle: after writing
+ * VALUES in place call bmsp_matrix_invalidate(m, 0) before the next product (drops the dense tile copies the block-MAC kernels read);
+ * after changing keys / bitmaps / offsets call it with structure_changed = 1 (drops the block-row pointer, SpMV plan and position
+ * cache, block records too).  Synchronises the device.  SpMV reads values directly: a value-only update needs no call for it. */
+int bmsp_matrix_invalidate(bmsp_matrix_t m, int structure_changed);
 /* dense block-row pointer (num_block_rows+1 uint32 entries) the operators use; built once and cached
  * (the reference rebuilds a compressed one on every call, src/bmSparse_SPMV.cu:199-206). */
 int bmsp_matrix_block_row_ptr(bmsp_matrix_t m, const uint32_t **d_rowptr, int64_t *num_block_rows);
@@ -242,7 +248,20 @@ int bmsp_comm_init(const void *id_bytes, int world, int rank, bmsp_comm_t *out);
 /* the same from the environment, for the drop-in executables: BMSP_WORLD, BMSP_RANK and, when BMSP_WORLD > 1, BMSP_COMM_FILE (a path
  * every rank can reach: rank 0 writes the id there, the others wait for it) */
 int bmsp_comm_init_from_env(bmsp_comm_t *out);
+/* BMSP_COMM_NONCE (optional, a number the launcher gives every rank of one run) is written into / required from the rendezvous file;
+ * rank 0 removes a pre-existing file first, readers refuse files without this run's nonce (and, when no nonce is set, files older than
+ * 120 s), so a file left by a crashed run is never joined. */
+/* An in-process "communicator" of `world` panels on the CURRENT device, no RCCL: bmsp_spgemm_sharded / bmsp_spmv_sharded then compute
+ * the `world` panels one after another and move every panel into its slice with a device copy.  It shares the size gather -> slice
+ * layout -> offset re-basing -> terminal offset code with the RCCL transport (only the byte movement differs): the way to run the
+ * sharded operators' P > 1 logic on one GPU.  Nothing in the reference to replace (single-GPU). */
+int bmsp_comm_init_loopback(int world, bmsp_comm_t *out);
 int bmsp_comm_info(bmsp_comm_t c, int *rank, int *world);
+/* The slice-layout arithmetic of the two exchanges, host only (no GPU call): where panel r of the sharded product lands in the whole C
+ * (block_start / value_start: parts+1 entries, exclusive sums of the panels' block / value counts; offsets of panel r are re-based by
+ * value_start[r]), and which rows of u panel r = block-rows [bounds[r], bounds[r+1]) delivers. */
+int bmsp_shard_layout(int parts, const int64_t *block_nums, const int64_t *nnzs, int64_t *block_start, int64_t *value_start);
+int bmsp_shard_row_slices(int num_rows, int parts, const int64_t *bounds, int64_t *row_start, int64_t *row_count);
 int bmsp_comm_free(bmsp_comm_t c);
 
 typedef struct {
@@ -258,8 +277,8 @@ typedef struct {
  * slices (an allgatherv without padding or staging copies), offsets re-based in place.  stats = this rank's panel product. */
 int bmsp_spgemm_sharded(bmsp_comm_t c, bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, int verbose,
                         void *stream, bmsp_spgemm_stats *stats, bmsp_shard_stats *shard);
-/* u = A * v with A cut into block-row panels balanced by stored values, v replicated; every rank sweeps its panel and all ranks
- * return the whole u (num_rows entries).  The panel view and its sweep plan are cached on A across calls. */
+/* u = A * v with A cut into block-row panels balanced by stored values, v replicated; every rank sweeps its panel (writing only its
+ * own rows of u), the row slices are exchanged in place and all ranks return the whole u (num_rows entries).  The panel view and its sweep plan are cached on A across calls. */
 int bmsp_spmv_sharded(bmsp_comm_t c, bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *stream, bmsp_shard_stats *shard);
 
 /* ---- host CSR (class CSRMatrix, include/CSRMatrix.h:13-21; declared only in the reference; backed by

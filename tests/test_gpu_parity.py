@@ -768,19 +768,30 @@ def test_spgemm_properties_large(bmsp):
         np.testing.assert_allclose(vv, ref.data[order], rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("case", ["2cubes_sphere_like", "cage12_like"])
-def test_spgemm_bench_size_properties(bmsp, case):
-    """the two SpGEMM bench workloads at their full BASELINE.json sizes, through size-independent properties: the three sort
+@pytest.mark.parametrize("case", ["2cubes_sphere_like", "cage12_like", "fem_like_27pt"])
+def test_spgemm_bench_size_properties(bmsp, oracle, case):
+    """the SpGEMM bench workloads at their full BASELINE.json sizes, through size-independent properties: the three sort
     modes give bit-identical C (V15 numerics); C's pattern is scipy's pattern product; C*1 == A*(A*1) through the SpMV; the fp16
-    MFMA product agrees with the fp32 one within the stated fp16 tolerance."""
+    MFMA product agrees with the fp32 one within the stated fp16 tolerance.  `fem_like_27pt` is the very workload bench.py times for
+    configs[2] (fem_like(47, "27pt"): 24.7 M surviving tasks, 14 per C tile -- the regime of the direct / strip block-MAC kernels and of
+    the read-back-free register sort); for it the oracle runs once at full size too (about a minute of host time): stage counters, C
+    structure and the fp32 V15 values bit for bit."""
     import scipy.sparse as sp
     from pybmsp import gen
-    n, _, r, c, v = gen.banded(101492, 8) if case == "2cubes_sphere_like" else gen.cage_like(130228, 15.6)
+    n, _, r, c, v = {"2cubes_sphere_like": lambda: gen.banded(101492, 8), "cage12_like": lambda: gen.cage_like(130228, 15.6),
+                     "fem_like_27pt": lambda: gen.fem_like(47, "27pt")}[case]()
     v = np.round(np.asarray(v) * 64) / 64          # exactly representable in fp16 and fp32
     A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
     At = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True)
     ref, st0 = bmsp.spgemm(A, At, mode=0, tc_version=5)
     ref_arrays = ref.host_arrays()
+    if case == "fem_like_27pt":
+        oc, ost = oracle.spgemm(oracle.bmsp_from_coo(oracle.Coo(n, n, r, c, v), oracle.F32, False),
+                                oracle.bmsp_from_coo(oracle.Coo(n, n, r, c, v), oracle.F32, True))
+        assert (st0["task_list_size"], st0["bmp_reduction"], st0["surviving_tasks"], st0["c_blocks"], st0["c_nnz"]) == \
+               (ost["task_list_size"], ost["bmp_reduction"], ost["surviving_tasks"], ost["c_blocks"], ost["c_nnz"])
+        util.assert_bmsp_equal_exact(oc, *ref_arrays, np.float32)
+        del oc
     for mode in (1, 2):
         Cm, st = bmsp.spgemm(A, At, mode=mode, tc_version=5)
         assert (st["task_list_size"], st["surviving_tasks"], st["c_blocks"], st["c_nnz"]) == \
@@ -948,6 +959,94 @@ def test_sharded_operators_through_c_abi_one_rank(oracle, bmsp):
         np.testing.assert_array_equal(y1.to_host(), y0)
     assert sh["exchange_bytes"] == 4 * n
     comm.free()
+
+
+def _hub_matrix(gen, kind):
+    """two skewed inputs for the sharded operators.  "rmat": R-MAT with a quarter of the block-rows empty and a hub row on top (panel
+    sizes differ by far more than 2x).  "diag": a diagonal plus one hub row that alone carries half of the candidate tasks, so that an
+    8-way split by candidate-task count leaves panels with NO block-row at all (bounds repeat) -- the empty-panel legs."""
+    if kind == "rmat":
+        n, _, r, c, v = gen.rmat(11, 6, seed=7)
+        keep = (r < n // 4) | (r >= n // 2)
+        r, c, v = r[keep], c[keep], v[keep]
+    else:
+        n = 2048
+        r = np.arange(n, dtype=np.int32); c = r.copy(); v = 0.5 + (r % 7) / 8.0
+    hub_c = np.arange(0, n, 3, dtype=r.dtype)
+    r = np.concatenate([r, np.full(hub_c.size, 5, dtype=r.dtype)])
+    c = np.concatenate([c, hub_c])
+    v = np.concatenate([v, np.linspace(0.25, 1.0, hub_c.size)])
+    key = r.astype(np.int64) * n + c
+    _, first = np.unique(key, return_index=True)
+    return n, r[first], c[first], np.round(v[first] * 64) / 64
+
+
+@pytest.mark.parametrize("kind", ["rmat", "diag"])
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_sharded_operators_loopback(bmsp, P, kind):
+    """every P > 1 branch of csrc/comm.hip on one device: the loopback transport computes the P panel products one after another and
+    moves each panel into its final slice with a device copy; size gather -> slice starts (shard_layout) -> AddU64 re-basing for
+    r > 0 -> terminal offset are the RCCL path's own lines.  Results must equal the unsharded operators bit for bit -- fp32 V15 and
+    fp16 MFMA, skewed panels, empty panels ("diag", P = 8), a ragged last block-row, a rectangular product, and the SpMV's slice-only
+    sweeps into NaN-poisoned vectors."""
+    from pybmsp import gen
+    comm = bmsp.Comm.loopback(P)
+    n, r, c, v = _hub_matrix(gen, kind)
+    n_rows = n - 5                                 # ragged last block-row
+    keep = r < n_rows
+    r, c, v = r[keep], c[keep], v[keep]
+    for dtype, tc in ((0, 5), (1, 4)):
+        A = bmsp.BmSpMatrix.from_coo(n_rows, n, r, c, v, dtype=dtype)
+        Bt = bmsp.BmSpMatrix.from_coo(n, n_rows, c, r, v, transposed=True, dtype=dtype)   # B = A^T: a rectangular product
+        whole, st0 = bmsp.spgemm(A, Bt, tc_version=tc)
+        bounds = bmsp.partition_rows(A, Bt, P)
+        if kind == "diag" and P == 8:
+            assert np.any(np.diff(bounds) == 0), bounds     # the construction's point: panels without a single block-row
+        Cs, st, sh = bmsp.spgemm_sharded(comm, A, Bt, tc_version=tc)
+        assert sh["world"] == P and st["surviving_tasks"] == st0["surviving_tasks"] and st["c_blocks"] == st0["c_blocks"]
+        assert sh["exchange_bytes"] == 24 * whole.block_num + 4 * whole.nnz
+        for x, y in zip(Cs.host_arrays(), whole.host_arrays()):
+            np.testing.assert_array_equal(x, y)
+    Af = bmsp.BmSpMatrix.from_coo(n_rows, n, r, c, v)
+    x = bmsp.DeviceArray.from_host(gen.spmv_x(n, "cusp"))
+    for variant in (0, 1):
+        y1 = bmsp.DeviceArray.from_host(np.full(n_rows, np.nan, np.float32))
+        y1, sh = bmsp.spmv_sharded(comm, Af, x, y1, variant=variant)
+        ref = bmsp.spmv(Af, x, batched=bool(variant)).to_host()
+        np.testing.assert_array_equal(y1.to_host(), ref)
+        assert sh["exchange_bytes"] == 4 * n_rows
+    comm.free()
+
+
+def test_matrix_invalidate_after_value_update(oracle, bmsp):
+    """the dense tile copies the block-MAC kernels read are cached on the handle and the value array is writable
+    (bmsp_matrix_arrays) -- multiply, overwrite the values in place, bmsp_matrix_invalidate, multiply again: the second product must be
+    the oracle's product of the NEW values (fp16 tc 4 and tc 5 both read the copies), also for a handle that borrows its arrays."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(10, 6, seed=5)
+    v = np.round(v * 16) / 16
+    v2 = np.round((1.0 - v) * 16) / 16 + 0.0625
+    for borrowed in (False, True):
+        A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=bmsp.F16)
+        Bt = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=bmsp.F16)
+        if borrowed:
+            ka, ba, oa, va = A.device_arrays()
+            A = bmsp.BmSpMatrix.from_device_arrays(n, n, ka, ba, oa, va, dtype=bmsp.F16)
+        for tc in (4, 5):
+            bmsp.spgemm(A, Bt, tc_version=tc)      # builds and caches the copies of the OLD values
+        # new values through the public arrays (same structure): A2 / B2 are built only to get the new value arrays in tile order
+        A2 = bmsp.BmSpMatrix.from_coo(n, n, r, c, v2, dtype=bmsp.F16)
+        B2 = bmsp.BmSpMatrix.from_coo(n, n, r, c, v2, transposed=True, dtype=bmsp.F16)
+        for dst, src in ((A, A2), (Bt, B2)):
+            d, s = dst.device_arrays()[3], src.device_arrays()[3]
+            bmsp.check(bmsp.lib().bmsp_memcpy_d2d(d.ptr, s.ptr, d.n * 2))
+            dst.invalidate()
+        oa_ = oracle.bmsp_from_coo(oracle.Coo(n, n, r, c, v2), oracle.F16, False)
+        ob_ = oracle.bmsp_from_coo(oracle.Coo(n, n, r, c, v2), oracle.F16, True)
+        for tc in (4, 5):
+            Cm, _ = bmsp.spgemm(A, Bt, tc_version=tc)
+            oc, _ = oracle.spgemm(oa_, ob_, exact_products=(tc != 5))
+            util.assert_bmsp_equal_exact(oc, *Cm.host_arrays(), np.float32)   # multiples of 1/256: every path is exact
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
