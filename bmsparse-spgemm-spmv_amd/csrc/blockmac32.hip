@@ -345,13 +345,28 @@ __global__ __launch_bounds__(kThreads, 4) void block_mac_mfma32_kernel(Mac32Args
 //   cage-like (1.2) 428 -> 652: pairs of tiles with unequal, small task counts leave most operand slots empty, so the launcher takes this
 //   kernel at >= 4.6 tasks per C tile only.  Running the two diagonal blocks as independent tile streams (no max(n0, n1)) was slower on
 //   every case (FEM-like 666, banded 69): the streams' tiles are half a quota apart and stop sharing A / B lines in the L1.
+// Round 3: the pipeline moves BLOCKS of U steps (a lane's task words of U steps in one request group, then its 2 U operand lines, then
+// U MFMAs), because a wave's loads return in order and the wait for the youngest request drains the older ones: with one step per
+// stage every step cost a full memory round trip (profiles/r02d: 73 % of the wave cycles parked in s_waitcnt).  The C bitmap and value
+// offset of the lane's tile are requested when the pair is ENTERED (two blocks ahead), not when it completes -- the store used to stall
+// on them with every newer request in flight.
 typedef uint32_t u32x2v_t __attribute__((ext_vector_type(2)));
 struct DirectPos {
     uint32_t c;       // first tile of the pair
-    uint32_t s, steps;
+    uint32_t s, steps;  // first step of the block; steps of the pair
     uint32_t tb, n;   // per lane: first task and task count of the lane's tile of the pair
+    uint64_t cb, co;  // per lane: C bitmap and value offset of the tile this lane stores (accumulator lanes only)
+};
+template <int U>
+struct DirectTasks {
+    uint64_t t[U];
+};
+template <int U>
+struct DirectLines {
+    half8_t a[U], b[U];
 };
 
+template <int U>
 __global__ __launch_bounds__(kThreads) void block_mac_direct_kernel(Mac32Args g)
 {
     const int w = wave_id(), lane = lane_id();
@@ -374,8 +389,10 @@ __global__ __launch_bounds__(kThreads) void block_mac_direct_kernel(Mac32Args g)
     }
     const uint32_t c0 = rl(rs, 0), ce = rl(rs, 1);
     if (c0 >= ce) return;
+    const int dt = lane >> 5;
+    const bool d_lane = dt == sel;
 
-    // a pair's words: task_begin[c .. c + 2] (wave-uniform scalar loads), the lane's tile = c + sel
+    // a pair's words: task_begin[c .. c + 2] (wave-uniform scalar loads), the lane's tile = c + sel; C words of the tile it will store
     auto enter = [&](uint32_t c) {
         DirectPos p;
         p.c = c;
@@ -385,62 +402,74 @@ __global__ __launch_bounds__(kThreads) void block_mac_direct_kernel(Mac32Args g)
         p.steps = (max(n0, n1) + 3u) / 4u;
         p.tb = sel ? t1 : t0;
         p.n = sel ? n1 : n0;
+        p.cb = 0; p.co = 0;
+        if (d_lane && c + (uint32_t)dt < ce) { p.cb = g.c_bmps[c + (uint32_t)dt]; p.co = g.c_offs[c + (uint32_t)dt]; }
         return p;
     };
     auto advance = [&](const DirectPos &p) {
         DirectPos q = p;
-        q.s = p.s + 1;
+        q.s = p.s + (uint32_t)U;
         if (q.s >= p.steps) {
             if (p.c + 2 < ce) q = enter(p.c + 2);
-            else { q.c = ce; q.s = 0; q.steps = 0; q.tb = 0; q.n = 0; }  // past the end: its loads are masked off
+            else { q.c = ce; q.s = 0; q.steps = 0; q.tb = 0; q.n = 0; q.cb = 0; q.co = 0; }  // past the end: its loads are masked off
         }
         return q;
     };
-    auto load_task = [&](const DirectPos &p) -> uint64_t {
-        const uint32_t ti = 4u * p.s + (uint32_t)ks;
-        const u32x2v_t t = __builtin_amdgcn_raw_buffer_load_b64(rtk, (p.c < ce && ti < p.n) ? (p.tb + ti) * 8u : kOob, 0, 0);
-        return ((uint64_t)t[1] << 32) | t[0];
+    auto load_tasks = [&](const DirectPos &p) {
+        DirectTasks<U> k;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t ti = 4u * (p.s + (uint32_t)u) + (uint32_t)ks;
+            const u32x2v_t t = __builtin_amdgcn_raw_buffer_load_b64(rtk, (p.c < ce && ti < p.n) ? (p.tb + ti) * 8u : kOob, 0, 0);
+            k.t[u] = ((uint64_t)t[1] << 32) | t[0];
+        }
+        return k;
     };
-    auto lines = [&](const DirectPos &p, uint64_t tk, half8_t &fa, half8_t &fb) {
-        const bool on = p.c < ce && 4u * p.s + (uint32_t)ks < p.n;
-        fa = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rda, on ? ((uint32_t)(tk >> 32) << 7) + (uint32_t)(r * 16) : kOob, 0, 0));
-        fb = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rdb, on ? ((uint32_t)tk << 7) + (uint32_t)(r * 16) : kOob, 0, 0));
+    auto load_lines = [&](const DirectPos &p, const DirectTasks<U> &k) {
+        DirectLines<U> o;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool on = p.c < ce && 4u * (p.s + (uint32_t)u) + (uint32_t)ks < p.n;
+            o.a[u] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rda, on ? ((uint32_t)(k.t[u] >> 32) << 7) + (uint32_t)(r * 16) : kOob, 0, 0));
+            o.b[u] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rdb, on ? ((uint32_t)k.t[u] << 7) + (uint32_t)(r * 16) : kOob, 0, 0));
+        }
+        return o;
     };
 
     DirectPos pa = enter(c0);
-    uint64_t tka = load_task(pa);
+    DirectTasks<U> tka = load_tasks(pa);
     DirectPos pb = advance(pa);
-    uint64_t tkb = load_task(pb);
-    half8_t fa, fb;
-    lines(pa, tka, fa, fb);
+    DirectTasks<U> tkb = load_tasks(pb);
+    DirectLines<U> oa = load_lines(pa, tka);
     float4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const int dt = lane >> 5;
-    const bool d_lane = dt == sel;
 
     while (pa.c < ce) {
-        // lines of the next step, task word of the one after
-        half8_t na, nb;
-        lines(pb, tkb, na, nb);
+        // lines of the next block, task words of the one after; then this block's instructions
+        const DirectLines<U> ob = load_lines(pb, tkb);
         const DirectPos pc = advance(pb);
-        const uint64_t tkc = load_task(pc);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
-        if (pa.s + 1 == pa.steps) {
-            // the pair is complete: compacted store by the C bitmap of the lane's tile
-            const uint32_t ct = pa.c + (uint32_t)dt;
-            if (d_lane && ct < ce) {
-                const uint64_t cb = g.c_bmps[ct], co = g.c_offs[ct];
-                const uint32_t row0 = 4u * (uint32_t)((lane >> 4) & 1);
+        const DirectTasks<U> tkc = load_tasks(pc);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t p = (row0 + (uint32_t)i) * 8u + (uint32_t)r;
-                    if ((cb >> (63u - p)) & 1ull) g.c_vals[co + (uint64_t)__popcll(cb >> 1 >> (63u - p))] = acc[i];
+        for (int u = 0; u < U; u++) {
+            if (pa.s + (uint32_t)u < pa.steps) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(oa.a[u], oa.b[u], acc, 0, 0, 0);
+                if (pa.s + (uint32_t)u + 1 == pa.steps) {
+                    // the pair is complete: compacted store by the C bitmap of the lane's tile
+                    if (d_lane && pa.c + (uint32_t)dt < ce) {
+                        const uint64_t cb = pa.cb, co = pa.co;
+                        const uint32_t row0 = 4u * (uint32_t)((lane >> 4) & 1);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const uint32_t p = (row0 + (uint32_t)i) * 8u + (uint32_t)r;
+                            if ((cb >> (63u - p)) & 1ull) g.c_vals[co + (uint64_t)__popcll(cb >> 1 >> (63u - p))] = acc[i];
+                        }
+                    }
+                    acc = float4_t{0.f, 0.f, 0.f, 0.f};
                 }
             }
-            acc = float4_t{0.f, 0.f, 0.f, 0.f};
         }
         pa = pb; pb = pc;
         tkb = tkc;
-        fa = na; fb = nb;
+        oa = ob;
     }
 }
 
@@ -498,11 +527,11 @@ bool mac_mfma32_b_dense(const bmsp_matrix_s *B)
     return full_tiles || (uint64_t)B->block_num * 128ull <= (4ull << 30);
 }
 
-void launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *task_begin, const uint32_t *c_of_wave, bmsp_matrix_s *A,
-                       bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st)
+int launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *task_begin, const uint32_t *c_of_wave, bmsp_matrix_s *A,
+                      bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st)
 {
     const uint32_t cs = (uint32_t)C->block_num;
-    if (!cs) return;
+    if (!cs) return BMSP_MAC_STAGED;
     ensure_dense_tiles(A, st);
     const bool b_dense = mac_mfma32_b_dense(B);
     if (b_dense) ensure_dense_tiles(B, st);
@@ -533,7 +562,12 @@ void launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *
     // >= 4.6 tasks per C tile: the direct kernel (no LDS); sparser task lists keep the staged one (BMSP_MAC_DIRECT = 0 / 1 forces)
     const char *de = getenv("BMSP_MAC_DIRECT");
     const bool direct = b_dense && (de ? de[0] == '1' : 10 * n_tasks >= 46 * (uint64_t)cs);
-    if (direct) hipLaunchKernelGGL(block_mac_direct_kernel, dim3(grid), dim3(kThreads), 0, st, g);
+    const char *ue = getenv("BMSP_MAC_DIRECT_U");  // experiment switch: steps per pipeline block (1, 2, 4)
+    const int du = ue ? atoi(ue) : 1;  // measured on MI355X (FEM-like / dense ceiling T_7, us): U = 1: 574 / 1631, 2: 640 / 1590, 4: 696 / 1596 -- the kernel is bound by the fabric
+                                         // rate of its 128-byte line gathers (~11 TB/s), not by round trips, so deeper blocks only cost occupancy
+    if (direct && du == 4) hipLaunchKernelGGL(block_mac_direct_kernel<4>, dim3(grid), dim3(kThreads), 0, st, g);
+    else if (direct && du == 2) hipLaunchKernelGGL(block_mac_direct_kernel<2>, dim3(grid), dim3(kThreads), 0, st, g);
+    else if (direct) hipLaunchKernelGGL(block_mac_direct_kernel<1>, dim3(grid), dim3(kThreads), 0, st, g);
     else if (b_dense) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, true, 0>), dim3(grid), dim3(kThreads), 0, st, g);
     else if (v == 4) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 4>), dim3(grid), dim3(kThreads), 0, st, g);
     else if (v == 8) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 8>), dim3(grid), dim3(kThreads), 0, st, g);
@@ -541,6 +575,7 @@ void launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *
     else if (v == 28) hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 28>), dim3(grid), dim3(kThreads), 0, st, g);
     else hipLaunchKernelGGL((block_mac_mfma32_kernel<kW, false, 0>), dim3(grid), dim3(kThreads), 0, st, g);
     BMSP_CHECK_LAUNCH();
+    return direct ? BMSP_MAC_DIRECT : BMSP_MAC_STAGED;
 }
 
 // runs the lane-layout self test; returns the number of mismatching elements of the 16x16 result

@@ -1,0 +1,413 @@
+// blockmac_strip.hip -- T_7 on the matrix cores, formulated around OPERAND REUSE: one wave owns a strip of two consecutive block-rows
+// of C and walks the product row-wise (Gustavson order), k-group by k-group.
+//
+// Reference: the tensor-core block-MAC kernels multiplyV11..V14 (src/bmSparse_SPGEMM.cu:294-733) stage both tiles of every task
+// (:238-276), and so did every kernel here until round 3 (blockmac32.hip): 256 bytes of operand lines per 1024-flop task and half of
+// every MFMA wasted on the block-diagonal packing.  Here
+//   * the strip's A tiles are the A operand of v_mfma_f32_16x16x32_f16 itself -- rows 0-7 = A(i0, k), rows 8-15 = A(i1, k), four k
+//     (a "k-group": four consecutive entries of the merged column list of the two block-rows) along K -- loaded ONCE per k-group and
+//     window and kept in registers while the B tiles stream by;
+//   * a B tile B(k, j) is loaded ONCE per strip and serves both block-rows: columns 0-7 = B(k, j_2p), columns 8-15 = B(k, j_2p+1);
+//     where both block-rows hold A(., k) all four 8x8 quadrants of the 16x16 result are real C tiles (16 block products per
+//     instruction instead of 8);
+//   * the accumulators of a WINDOW of 32 consecutive C-tile columns of the strip (16 column pairs x 4 VGPRs) stay in registers while
+//     every k-group passes; C tiles are written exactly once, compacted by their bitmap.
+// The kernel reads the operands' structure (A / B block-row pointers and keys), C's structure (keys, bitmaps, offsets and a block-row
+// pointer) and the dense fp16 tile copies; it does NOT read the sorted task list -- the symbolic stages T_3 ... T_9 have fixed what C
+// holds, the numeric stage recomputes which (k, j) meet from the two operands.  A candidate pair the bitmap filter dropped
+// (multiplication_checker, :742-757) is skipped here by the same test on the cached row / column masks; where it is multiplied
+// anyway (the other block-row of the strip needs the tile) its dense product is exactly zero.  Summation order inside a C tile: k
+// ascending in groups of four, inside the MFMA in hardware order -- the matrix-core numerics of tc_version 1..4 (exact fp16 products,
+// fp32 accumulation; tolerance stated in the tests), never V15's.
+//
+// Per wave (LDS): the merged k list of the strip {k, A tile of row 0 / row 1, cursor and end of B's block-row k, column mask}, the
+// merged column list of the strip's C tiles {j, C tile of row 0 / row 1}, and a 4 x 32 schedule table of the current (window,
+// k-group).  Per (window, k-group): 16 lanes per k walk B's block-row k from its cursor (coalesced keys + bitmaps, requested one
+// k-group ahead), binary-search the window's columns in LDS and scatter the tile index into the schedule; the MFMA lanes then fetch
+// their B line (one 16-byte line per lane) for up to four active column pairs at a time and issue the MFMAs.
+//
+// Limits (the launcher checks them and keeps the task-list kernels of blockmac32.hip otherwise): <= kKCap merged A tiles and <= kJCap
+// merged C tiles per strip, finite operand values (a skipped pair's product must be an exact zero), 32-bit byte offsets.
+#include "mac_common.hip.h"
+
+namespace bmsp {
+namespace {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+constexpr int kKCap = 192;  // merged A tiles of a strip (two block-rows)
+constexpr int kJCap = 512;  // merged C tiles of a strip
+constexpr uint32_t kNone = 0xffffffffu;
+
+struct StripArgs {
+    const uint64_t *a_keys, *a_bmps;
+    const uint32_t *a_rowptr;
+    const _Float16 *a_dense;
+    uint32_t a_dense_bytes;
+    const uint64_t *b_keys, *b_bmps;
+    const uint32_t *b_rowptr;
+    const _Float16 *b_dense;
+    uint32_t b_dense_bytes, b_block_rows;
+    const uint64_t *c_keys, *c_bmps, *c_offs;
+    const uint32_t *c_rowptr;
+    float *c_vals;
+    uint32_t block_rows;  // of A and C
+};
+
+struct StripLds {
+    uint32_t jj[kJCap];        // merged column list of the strip's C tiles
+    uint16_t jc[kJCap][2];     // C tile of row 0 / row 1 relative to the row's first tile; 0xffff = none
+    uint32_t kk[kKCap];        // merged k list
+    uint32_t ka[kKCap][2];     // A tile of row 0 / row 1 (absolute index; kNone)
+    uint32_t kcur[kKCap];      // B's block-row k: next tile not yet consumed
+    uint32_t kend[kKCap];
+    uint32_t kcm[kKCap];       // OR of the column masks of the strip's A tiles in column k
+    uint32_t l0[kJCap / 2], l1[kJCap / 2];  // merge temporaries (the two sorted lists)
+    uint16_t nd[kJCap / 2 + 2];             // non-duplicates among the first q entries of l1
+    uint32_t sched[2][4][2][16];  // two tables (item n & 1) x [k slot][column of the pair][pair]: B tile index + 1; 0 = none
+    uint32_t pmask[2];            // column pairs of the item's window with any tile of its k-group
+};
+
+__device__ __forceinline__ uint32_t lds_lower_bound(const uint32_t *a, uint32_t n, uint32_t v)
+{  // first index with a[idx] >= v
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// merges the sorted lists l0[0..n0) and l1[0..n1) of S (duplicates across the lists collapse); emit(pos, value, idx0 or kNone, idx1 or
+// kNone) is called once per list element (an element present in both lists is emitted twice with the same pos, once per side);
+// returns the length of the merged list.  Wave-wide; l0 / l1 / nd live in LDS.
+template <typename Emit>
+__device__ __forceinline__ uint32_t merge_sorted(StripLds &S, uint32_t n0, uint32_t n1, int lane, Emit emit)
+{
+    // non-duplicate prefix counts of l1
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n1; base += 64) {
+        const uint32_t q = base + (uint32_t)lane;
+        bool nondup = false;
+        if (q < n1) {
+            const uint32_t y = S.l1[q];
+            const uint32_t p = lds_lower_bound(S.l0, n0, y);
+            nondup = !(p < n0 && S.l0[p] == y);
+        }
+        const uint64_t bal = __ballot(nondup);
+        if (q < n1) S.nd[q] = (uint16_t)(carry + (uint32_t)__popcll(bal & lanemask_lt()));
+        carry += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) S.nd[n1] = (uint16_t)carry;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < n0; base += 64) {
+        const uint32_t p = base + (uint32_t)lane;
+        if (p < n0) {
+            const uint32_t x = S.l0[p];
+            emit(p + (uint32_t)S.nd[lds_lower_bound(S.l1, n1, x)], x, p, kNone);
+        }
+    }
+    for (uint32_t base = 0; base < n1; base += 64) {
+        const uint32_t q = base + (uint32_t)lane;
+        if (q < n1) {
+            const uint32_t y = S.l1[q];
+            const uint32_t p = lds_lower_bound(S.l0, n0, y);  // for a duplicate: its index in l0
+            emit(p + (uint32_t)S.nd[q], y, kNone, q);
+        }
+    }
+    return n0 + carry;
+}
+
+// what a k-group's scan needs from memory, requested one k-group ahead: keys and bitmaps of the next 32 tiles of B's block-row k
+struct ScanPre {
+    uint64_t key[2], bmp[2];
+    uint32_t cur, end;
+};
+
+// NB = B lines (column pairs) a wave keeps in flight, OCC = waves per SIMD the register allocation is held to
+template <int NB, int OCC>
+__global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArgs g)
+{
+    __shared__ StripLds lds_all[4];
+    const int w = wave_id(), lane = lane_id();
+    StripLds &S = lds_all[w];
+    // XCD-aware order (as in blockmac32.hip): the workgroups of one XCD take a contiguous eighth of the strips, so that neighbouring
+    // strips -- which read the same block-rows of B -- meet in the same L2
+    uint32_t wg;
+    {
+        const uint32_t G = gridDim.x, q = G / 8, rm = G % 8, x = blockIdx.x % 8;
+        wg = (x < rm ? x * (q + 1) : rm * (q + 1) + (x - rm) * q) + blockIdx.x / 8;
+    }
+    const uint32_t strip = wg * 4 + (uint32_t)w;
+    const uint32_t i0 = 2 * strip;
+    if (i0 >= g.block_rows) return;
+    const bool two = i0 + 1 < g.block_rows;
+    const rsrc_t rda = make_rsrc(g.a_dense, g.a_dense_bytes), rdb = make_rsrc(g.b_dense, g.b_dense_bytes);
+
+    // ---- the strip's rows of A and C ----
+    const uint32_t a0b = g.a_rowptr[i0], a0e = g.a_rowptr[i0 + 1], a1e = two ? g.a_rowptr[i0 + 2] : a0e;
+    const uint32_t c0b = g.c_rowptr[i0], c0e = g.c_rowptr[i0 + 1], c1e = two ? g.c_rowptr[i0 + 2] : c0e;
+    const uint32_t n0 = a0e - a0b, n1 = a1e - a0e, m0 = c0e - c0b, m1 = c1e - c0e;
+    if (m0 + m1 == 0) return;  // no C tile in the strip: nothing to compute
+
+    // ---- merged k list ----
+    for (uint32_t p = (uint32_t)lane; p < n0; p += 64) S.l0[p] = key_col(g.a_keys[a0b + p]);
+    for (uint32_t q = (uint32_t)lane; q < n1; q += 64) S.l1[q] = key_col(g.a_keys[a0e + q]);
+    for (uint32_t u = (uint32_t)lane; u < (uint32_t)kKCap; u += 64) { S.ka[u][0] = kNone; S.ka[u][1] = kNone; S.kcm[u] = 0u; }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nK = merge_sorted(S, n0, n1, lane, [&](uint32_t pos, uint32_t k, uint32_t p, uint32_t q) {
+        const uint32_t a = p != kNone ? a0b + p : a0e + q;
+        S.kk[pos] = k;
+        S.ka[pos][p != kNone ? 0 : 1] = a;
+        atomicOr(&S.kcm[pos], tile_or_bytes(g.a_bmps[a]));  // column k' of the tile holds a value <=> bit (7 - k')
+    });
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t u = (uint32_t)lane; u < nK; u += 64) {
+        const uint32_t k = S.kk[u];
+        const bool in = k < g.b_block_rows;  // no matching block-row in B: no tile
+        S.kcur[u] = in ? g.b_rowptr[k] : 0u;
+        S.kend[u] = in ? g.b_rowptr[k + 1] : 0u;
+    }
+    // ---- merged column list of the strip's C tiles ----
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t p = (uint32_t)lane; p < m0; p += 64) S.l0[p] = key_col(g.c_keys[c0b + p]);
+    for (uint32_t q = (uint32_t)lane; q < m1; q += 64) S.l1[q] = key_col(g.c_keys[c0e + q]);
+    for (uint32_t s = (uint32_t)lane; s < (uint32_t)kJCap; s += 64) { S.jc[s][0] = 0xffffu; S.jc[s][1] = 0xffffu; }
+    for (uint32_t s = (uint32_t)lane; s < 256u; s += 64) ((uint32_t *)S.sched)[s] = 0u;
+    if (lane < 2) S.pmask[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nJ = merge_sorted(S, m0, m1, lane, [&](uint32_t pos, uint32_t j, uint32_t p, uint32_t q) {
+        S.jj[pos] = j;
+        if (p != kNone) S.jc[pos][0] = (uint16_t)p;
+        else S.jc[pos][1] = (uint16_t)q;
+    });
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- lane roles ----
+    const int ks = lane >> 4;                          // K slot of the MFMA = entry of the k-group
+    const int half_sel = (lane >> 3) & 1;              // A operand: block-row of the strip; B operand: column of the pair
+    const int line = lane & 7;                         // tile row (A) / tile column (B)
+    const int q16 = lane & 15;                         // scan: tile q16 / q16 + 16 behind the cursor of k slot ks
+    const int d_row = lane >> 5;                       // result: block-row of the strip this lane's D values belong to
+    const uint32_t d_r0 = 4u * (uint32_t)((lane >> 4) & 1);  // first of its four tile rows
+    const uint32_t nG = (nK + 3) / 4, nW = (nJ + 31) / 32;
+    if (nG == 0) return;  // (C tiles without an A tile cannot exist)
+
+    // one (window, k-group) of the walk = an "item"; items are taken window by window, k-group by k-group
+    struct Item {
+        uint32_t wi, gi;
+        bool on;
+    };
+    auto next_item = [&](Item it) {
+        it.gi++;
+        if (it.gi == nG) { it.gi = 0; it.wi++; }
+        it.on = it.on && it.wi < nW;
+        return it;
+    };
+    auto request = [&](const Item &it) {
+        ScanPre pre;
+        const uint32_t u = 4 * it.gi + (uint32_t)ks;
+        pre.cur = 0; pre.end = 0;
+        if (it.on && u < nK) { pre.cur = S.kcur[u]; pre.end = S.kend[u]; }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t t = pre.cur + (uint32_t)(16 * h + q16);
+            pre.key[h] = 0; pre.bmp[h] = 0;
+            if (t < pre.end) { pre.key[h] = g.b_keys[t]; pre.bmp[h] = g.b_bmps[t]; }
+        }
+        return pre;
+    };
+    // scan of an item into schedule table tb: the tiles of B's block-rows k (the item's k-group) that fall into the item's window.
+    // 16 lanes per k take 32 tiles behind the cursor (keys and bitmaps were requested one item ahead), find the tile's column among
+    // the window's C columns (directly when those are consecutive block columns, by binary search in LDS otherwise) and scatter the
+    // tile index
+    auto scan = [&](const Item &it, uint32_t tb, ScanPre &pre) {
+        if (!it.on) return;
+        const uint32_t s0 = 32 * it.wi, ns = min(32u, nJ - s0);
+        const uint32_t jlo = S.jj[s0], jhi = S.jj[s0 + ns - 1];
+        const bool dense_win = jhi - jlo == ns - 1u;
+        const uint32_t u = 4 * it.gi + (uint32_t)ks;
+        const bool u_on = u < nK;
+        const uint32_t cm = u_on ? S.kcm[u] : 0u;
+        for (;;) {
+            uint32_t hits = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t t = pre.cur + (uint32_t)(16 * h + q16);
+                const uint32_t j = key_col(pre.key[h]);
+                const bool inwin = t < pre.end && j <= jhi;
+                if (inwin) {
+                    uint32_t sl;
+                    bool found;
+                    if (dense_win) { sl = j - jlo; found = j >= jlo; }
+                    else { sl = lds_lower_bound(S.jj + s0, ns, j); found = sl < ns && S.jj[s0 + sl] == j; }
+                    // present in C's strip and not dropped by the bitmap filter (the tile's non-empty rows against the columns in use)
+                    if (found && (cm & tile_or_bytes(pre.bmp[h])) != 0u) {
+                        S.sched[tb][ks][sl & 1u][sl >> 1] = t + 1u;
+                        atomicOr(&S.pmask[tb], 1u << (sl >> 1));
+                    }
+                }
+                hits += (uint32_t)__popcll((__ballot(inwin) >> (16 * ks)) & 0xffffull);
+            }
+            pre.cur += hits;
+            if (!__any(hits == 32u)) break;
+            // every tile fetched for some k slot lay inside the window: there may be more of them
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t t = pre.cur + (uint32_t)(16 * h + q16);
+                pre.key[h] = 0; pre.bmp[h] = 0;
+                if (t < pre.end) { pre.key[h] = g.b_keys[t]; pre.bmp[h] = g.b_bmps[t]; }
+            }
+        }
+        if (u_on && q16 == 0) S.kcur[u] = pre.cur;
+    };
+
+    Item cur{0u, 0u, true};
+    Item nxt = next_item(cur);
+    ScanPre pre = request(cur);
+    scan(cur, 0u, pre);
+    __builtin_amdgcn_wave_barrier();
+    pre = request(nxt);
+    float4_t acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; p++) acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
+    uint32_t tb = 0;
+    while (cur.on) {
+        const uint32_t u = 4 * cur.gi + (uint32_t)ks;
+        // ---- requests of the item: the A operand (line `line` of A(row half_sel, k slot ks)) and the B lines of its first NB active
+        //      column pairs -- straight-line code (an absent pair's request goes out of range and moves nothing), so that the
+        //      compiler's wait counts stay exact.  The item's schedule was scattered one iteration ago. ----
+        const uint32_t a = u < nK ? S.ka[u][half_sel] : kNone;
+        const half8_t fa = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rda, a != kNone ? (a << 7) + (uint32_t)(line * 16) : kOob, 0, 0));
+        const uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.pmask[tb]);
+        const uint32_t *my = S.sched[tb][ks][half_sel];
+        const Item nn = next_item(nxt);
+        // while the item's B lines travel: the scan of the next item into the other table, and the key request of the one after
+        auto scan_next = [&]() {
+            scan(nxt, tb ^ 1u, pre);
+            __builtin_amdgcn_wave_barrier();
+            pre = request(nn);
+        };
+        // The column pairs are walked with STATIC indices (accumulator registers cannot be indexed; a switch over the pair number makes
+        // the compiler copy the accumulator file around every case) in batches of NB: requests of the batch's active pairs (wave-uniform
+        // branches), then -- once per item -- the next item's scan, then the batch's MFMAs.
+        bool scanned = false;
+#pragma unroll
+        for (int hb = 0; hb < 16 / NB; hb++) {
+            const uint32_t mb = (pm >> (NB * hb)) & ((1u << NB) - 1u);
+            if (mb) {
+                half8_t fb[NB];
+#pragma unroll
+                for (int q = 0; q < NB; q++) {
+                    if ((mb >> q) & 1u) {
+                        const uint32_t b1 = my[NB * hb + q];
+                        fb[q] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rdb, b1 ? ((b1 - 1u) << 7) + (uint32_t)(line * 16) : kOob, 0, 0));
+                    }
+                }
+                if (!scanned) { scan_next(); scanned = true; }
+#pragma unroll
+                for (int q = 0; q < NB; q++) {
+                    if ((mb >> q) & 1u) acc[NB * hb + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[q], acc[NB * hb + q], 0, 0, 0);
+                }
+            }
+        }
+        if (!scanned) scan_next();
+        __builtin_amdgcn_wave_barrier();
+        // clear the item's schedule (512 bytes: one 8-byte store per lane); the item after next will scatter into it
+        ((uint64_t *)S.sched[tb])[lane] = 0ull;
+        if (lane == 0) S.pmask[tb] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (cur.gi + 1 == nG) {
+            // ---- the window is complete: lane holds D[4 * (lane >> 4) + i][lane & 15] = rows d_r0 + i of C(row d_row, column 2p + half_sel) ----
+            const uint32_t s0 = 32 * cur.wi, ns = min(32u, nJ - s0);
+            const uint32_t crow0 = d_row ? c0e : c0b;
+#pragma unroll
+            for (int p = 0; p < 16; p++) {
+                const uint32_t sl = 2u * (uint32_t)p + (uint32_t)half_sel;
+                const uint32_t crel = sl < ns ? (uint32_t)S.jc[s0 + sl][d_row] : 0xffffu;
+                if (crel != 0xffffu) {
+                    const uint32_t c = crow0 + crel;
+                    const uint64_t cb = g.c_bmps[c], co = g.c_offs[c];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t pos = (d_r0 + (uint32_t)i) * 8u + (uint32_t)line;
+                        if ((cb >> (63u - pos)) & 1ull) g.c_vals[co + (uint64_t)__popcll(cb >> 1 >> (63u - pos))] = acc[p][i];
+                    }
+                }
+                acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        cur = nxt; nxt = nn;
+        tb ^= 1u;
+    }
+}
+
+// fp16 values that are not finite (exponent all ones): a skipped candidate pair must contribute an exact zero
+struct NonFiniteF16 {
+    const uint16_t *v;
+    uint32_t *flag;
+    __device__ void operator()(uint64_t i) const
+    {
+        if ((v[i] & 0x7c00u) == 0x7c00u) *flag = 1u;
+    }
+};
+
+}  // namespace
+
+void ensure_finite_flag(bmsp_matrix_s *m, hipStream_t st)
+{
+    if (m->values_finite >= 0) return;
+    if (m->dtype != BMSP_F16 || m->nnz == 0) { m->values_finite = 1; return; }
+    DevBuf<uint32_t> flag(1);
+    BMSP_HIP(hipMemsetAsync(flag.p, 0, 4, st));
+    const uint64_t base = m->view_values_end ? read_back(m->offsets, st) : 0;
+    device_for_each(NonFiniteF16{(const uint16_t *)m->values + base, flag.p}, (uint64_t)m->values_extent() - base, st);
+    m->values_finite = read_back(flag.p, st) ? 0 : 1;
+}
+
+// whether the strip kernel takes this product (decided from cached per-matrix figures; the two read-backs behind them happen once per matrix)
+bool mac_strip_eligible(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, uint64_t candidates, uint64_t n_tasks, hipStream_t st)
+{
+    const char *force = getenv("BMSP_MAC_STRIP");  // 0 / 1: experiment and test switch (the capacity limits below still hold)
+    if (force && force[0] == '0') return false;
+    if (!mac_mfma32_supported(A, B) || C->block_num >= (1ll << 31) || C->block_num == 0) return false;
+    if ((uint64_t)A->num_block_rows() >= (1ull << 31)) return false;
+    ensure_row_stats(A, st);
+    if (2 * A->max_row_blocks > kKCap) return false;
+    if (!force) {
+        // the walk visits every candidate pair: it pays when most of them survive the filter and C tiles collect several tasks each
+        if (10 * n_tasks < 46 * (uint64_t)C->block_num || 2 * n_tasks < candidates) return false;
+    }
+    ensure_row_stats(C, st);
+    if (2 * C->max_row_blocks > kJCap) return false;
+    ensure_finite_flag(A, st);
+    ensure_finite_flag(B, st);
+    return A->values_finite == 1 && B->values_finite == 1;
+}
+
+void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st)
+{
+    ensure_dense_tiles(A, st);
+    ensure_dense_tiles(B, st);
+    ensure_rowptr(A, st);
+    ensure_rowptr(B, st);
+    ensure_rowptr(C, st);
+    StripArgs g{};
+    g.a_keys = A->keys; g.a_bmps = A->bmps; g.a_rowptr = A->rowptr;
+    g.a_dense = (const _Float16 *)A->dense_tiles; g.a_dense_bytes = (uint32_t)(A->block_num * 128);
+    g.b_keys = B->keys; g.b_bmps = B->bmps; g.b_rowptr = B->rowptr;
+    g.b_dense = (const _Float16 *)B->dense_tiles; g.b_dense_bytes = (uint32_t)(B->block_num * 128);
+    g.b_block_rows = (uint32_t)B->num_block_rows();
+    g.c_keys = C->keys; g.c_bmps = C->bmps; g.c_offs = C->offsets; g.c_rowptr = C->rowptr; g.c_vals = (float *)C->values;
+    g.block_rows = (uint32_t)A->num_block_rows();
+    const uint32_t strips = (g.block_rows + 1) / 2;
+    const char *ve = getenv("BMSP_STRIP_VARIANT");  // experiment switch: B lines in flight / waves per SIMD = 0: 8 / 3, 1: 4 / 3, 2: 16 / 2
+    const int v = ve ? atoi(ve) : 0;
+    if (v == 1) hipLaunchKernelGGL((block_mac_strip_kernel<4, 3>), dim3((strips + 3) / 4), dim3(kThreads), 0, st, g);
+    else if (v == 2) hipLaunchKernelGGL((block_mac_strip_kernel<16, 2>), dim3((strips + 3) / 4), dim3(kThreads), 0, st, g);
+    else hipLaunchKernelGGL((block_mac_strip_kernel<8, 3>), dim3((strips + 3) / 4), dim3(kThreads), 0, st, g);
+    BMSP_CHECK_LAUNCH();
+}
+
+}  // namespace bmsp

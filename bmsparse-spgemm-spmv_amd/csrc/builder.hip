@@ -377,6 +377,7 @@ void free_matrix(bmsp_matrix_s *m)
     pool_free(m->spmv_pos);
     pool_free(m->block_meta);
     pool_free(m->dense_tiles);
+    pool_free(m->lane_tiles);
     free_matrix(m->shard_view);
     delete m;
 }
@@ -389,6 +390,8 @@ void invalidate_matrix(bmsp_matrix_s *m, int structure_changed)
     if (!m) return;
     BMSP_HIP(hipDeviceSynchronize());  // no kernel may still be reading what is about to go back to the pool
     pool_free(m->dense_tiles); m->dense_tiles = nullptr;
+    pool_free(m->lane_tiles); m->lane_tiles = nullptr;
+    m->values_finite = -1;
     if (!structure_changed) return;
     pool_free(m->rowptr); m->rowptr = nullptr; m->rowptr_rows = 0; m->max_row_blocks = -1;
     pool_free(m->spmv_chunks); m->spmv_chunks = nullptr; m->spmv_num_chunks = 0; m->spmv_plan_long = 0; m->spmv_full_tiles = 0;
@@ -460,6 +463,8 @@ void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st)
     if (m->dtype == BMSP_F16 && m->block_num < (1ll << 25) && (!m->transposed || mac_mfma32_b_dense(m))) ensure_dense_tiles(m, st);
     // V15 block-MAC (tc_version 5): fp32 operands with tiles at least a quarter full are staged from a dense copy too (256 B per block)
     if (m->dtype == BMSP_F32 && m->nnz >= 16 * m->block_num && (uint64_t)m->block_num * 256 <= (4ull << 30)) ensure_dense_tiles(m, st);
+    // fp32 MFMA block-MAC (tc_version 5 where the hardware self test passed): the tiles in MFMA lane order (256 B per block)
+    if (m->dtype == BMSP_F32 && m->block_num < (1ll << 24) && m->nnz >= 16 * m->block_num && mac_f32_mfma_usable(st)) ensure_lane_tiles(m, st);
 }
 
 bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, const int *d_rows, const int *d_cols,

@@ -470,6 +470,14 @@ int bmsp_spmv(bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *st
     BMSP_API_END
 }
 
+int bmsp_spmv_launch_info(bmsp_matrix_t A, int variant, char *kernel_name, size_t kernel_name_cap, int64_t *compulsory_bytes, int64_t *format_bytes)
+{
+    BMSP_API_BEGIN
+    need(A, "A");
+    spmv_launch_info(A, variant, nullptr, kernel_name, kernel_name_cap, compulsory_bytes, format_bytes);
+    BMSP_API_END
+}
+
 int bmsp_comm_unique_id(void *id_bytes)
 {
     BMSP_API_BEGIN
@@ -556,6 +564,14 @@ int bmsp_selftest_mfma_layout(int *mismatches)
     BMSP_API_BEGIN
     need(mismatches, "mismatches");
     *mismatches = mfma32_selftest(nullptr);
+    BMSP_API_END
+}
+
+int bmsp_selftest_mfma_f32_chain(int *mismatches)
+{
+    BMSP_API_BEGIN
+    need(mismatches, "mismatches");
+    *mismatches = mfma_f32_selftest(nullptr);
     BMSP_API_END
 }
 

@@ -300,7 +300,7 @@ void spgemm_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_mat
         ps.task_list_size += one.task_list_size; ps.bmp_reduction += one.bmp_reduction; ps.surviving_tasks += one.surviving_tasks;
         ps.c_blocks += one.c_blocks; ps.c_nnz += one.c_nnz;
         for (int i = 0; i < 10; i++) ps.t_us[i] += one.t_us[i];
-        ps.sort_path = one.sort_path; ps.mac_kernel = one.mac_kernel;
+        ps.sort_path = one.sort_path; ps.mac_kernel = one.mac_kernel; ps.mac_variant = one.mac_variant;
     }
     const bmsp_dtype cdt = A->dtype == BMSP_F64 ? BMSP_F64 : BMSP_F32;
     StageTimer tm(st, true);

@@ -35,6 +35,8 @@ struct bmsp_matrix_s {
     uint32_t *block_meta = nullptr;  // block_num x {bmp lo, bmp hi, offset in elements, 0}
     // fp16 matrices: every tile expanded to 64 halves in position order (128 B per block), for the K = 32 MFMA block-MAC: built lazily
     void *dense_tiles = nullptr;
+    void *lane_tiles = nullptr;   // fp32 matrices: tiles in the lane order of the fp32 MFMA block-MAC (256 B per block): built lazily
+    int values_finite = -1;       // fp16 operands of the strip block-MAC: 1 = no inf / NaN stored (-1 = not looked yet)
     // a row-panel view points into its parent
     int64_t view_block_begin = 0;
     // sharded SpMV (comm.hip): this rank's panel view, kept for its cached sweep plan
@@ -79,11 +81,18 @@ void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st);
 void ensure_row_stats(bmsp_matrix_s *m, hipStream_t st);
 void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st);
 void ensure_dense_tiles(bmsp_matrix_s *m, hipStream_t st);
+void ensure_lane_tiles(bmsp_matrix_s *m, hipStream_t st);
+bool mac_f32_mfma_usable(hipStream_t st);
 bool mac_mfma32_supported(const bmsp_matrix_s *A, const bmsp_matrix_s *B);
 bool mac_mfma32_b_dense(const bmsp_matrix_s *B);
-void launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *task_begin, const uint32_t *c_of_wave, bmsp_matrix_s *A,
-                       bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);
+int launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *task_begin, const uint32_t *c_of_wave, bmsp_matrix_s *A,
+                      bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);  // returns the variant it launched (BMSP_MAC_*)
 int mfma32_selftest(hipStream_t st);
+int mfma_f32_selftest(hipStream_t st);
+bool launch_mac_f32_mfma(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *task_begin, const uint32_t *c_of_wave, bmsp_matrix_s *A,
+                         bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);
+bool mac_strip_eligible(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, uint64_t candidates, uint64_t n_tasks, hipStream_t st);
+void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);
 void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st);
 void matrix_to_coo_device_split(bmsp_matrix_s *m, int *d_rows, int *d_cols, double *d_vals, hipStream_t st);
 void matrix_to_csr_device(bmsp_matrix_s *m, int *d_row_offsets, int *d_cols, double *d_vals, hipStream_t st);
@@ -97,6 +106,7 @@ void prepare_spmv(bmsp_matrix_s *m, hipStream_t st);
 void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st);
 
 void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st, int64_t row_lo = 0, int64_t row_hi = -1);
+void spmv_launch_info(bmsp_matrix_s *A, int variant, hipStream_t st, char *kernel, size_t kernel_cap, int64_t *compulsory, int64_t *format_bytes);
 void spmm(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, int k, hipStream_t st);
 void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int tc_version, int verbose, hipStream_t st,
             bmsp_spgemm_stats *stats);

@@ -150,7 +150,7 @@ void spgemm_paneled(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, in
             acc.task_list_size += ps.task_list_size; acc.bmp_reduction += ps.bmp_reduction; acc.surviving_tasks += ps.surviving_tasks;
             acc.c_blocks += ps.c_blocks; acc.c_nnz += ps.c_nnz;
             for (int i = 0; i < 10; i++) acc.t_us[i] += ps.t_us[i];
-            acc.sort_path = ps.sort_path; acc.mac_kernel = ps.mac_kernel;
+            acc.sort_path = ps.sort_path; acc.mac_kernel = ps.mac_kernel; acc.mac_variant = ps.mac_variant;
         }
         std::vector<int64_t> bn, nz;
         std::vector<uint64_t *> k, b, o;

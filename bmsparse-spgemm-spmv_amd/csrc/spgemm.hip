@@ -1081,7 +1081,13 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
             const uint32_t a_bytes = (uint32_t)(A->values_extent() * 2), b_bytes = (uint32_t)(B->values_extent() * 2);
             const bool old_mac = getenv("BMSP_MAC_OLD") != nullptr;  // experiment switch: the r1 16x16x16 group kernel
             if (tc_version == 4 && !old_mac && mac_mfma32_supported(A, B)) {
-                launch_mac_mfma32(vv.cur, n_tasks, task_begin.p, c_of_wave.p, A, B, C.get(), st);
+                // many tasks per C tile and most candidate pairs alive: the strip kernel (operand reuse; reads A, B, C, not the task list)
+                if (mac_strip_eligible(A, B, C.get(), total, n_tasks, st)) {
+                    launch_mac_strip(A, B, C.get(), st);
+                    S->mac_variant = BMSP_MAC_STRIP;
+                } else {
+                    S->mac_variant = launch_mac_mfma32(vv.cur, n_tasks, task_begin.p, c_of_wave.p, A, B, C.get(), st);
+                }
             } else if (tc_version == 4 && pool_owns(A->values) && pool_owns(B->values) && A->block_num < (1ll << 28) && B->block_num < (1ll << 28)) {
                 ensure_block_meta(A, st);
                 ensure_block_meta(B, st);
@@ -1100,7 +1106,8 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
             BMSP_CHECK_LAUNCH();
             S->mac_kernel = tc_version;
         } else {
-            if (A->dtype == BMSP_F32) launch_mac_valu<float>(vv.cur, task_begin.p, A, B, C.get(), st);
+            if (A->dtype == BMSP_F32 && launch_mac_f32_mfma(vv.cur, n_tasks, task_begin.p, c_of_wave.p, A, B, C.get(), st)) S->mac_variant = BMSP_MAC_F32MFMA;
+            else if (A->dtype == BMSP_F32) launch_mac_valu<float>(vv.cur, task_begin.p, A, B, C.get(), st);
             else if (A->dtype == BMSP_F16) launch_mac_valu<_Float16>(vv.cur, task_begin.p, A, B, C.get(), st);
             else launch_mac_valu<double>(vv.cur, task_begin.p, A, B, C.get(), st);
             S->mac_kernel = 5;

@@ -36,7 +36,9 @@
 #include "spmv_plan.h"
 #include "prims.hip.h"
 #include <cstdlib>
+#include <cstdio>
 #include <algorithm>
+#include <vector>
 
 namespace bmsp {
 namespace {
@@ -582,9 +584,9 @@ struct VsPre {
     A a[kPre];
 };
 // values of the item (short items carry their value range; a long-row item holds 256 tiles, its count is not in the plan)
-__device__ __forceinline__ uint32_t vs_item_values(const SweepItem &it) { return it.num_items == 0 ? it.first_item - it.val_begin : 64u * kPre; }
+__host__ __device__ __forceinline__ uint32_t vs_item_values(const SweepItem &it) { return it.num_items == 0 ? it.first_item - it.val_begin : 64u * kPre; }
 // the common case: the whole item is one batch, and the item says how many values that is -- no offset is read
-__device__ __forceinline__ bool vs_single(const SweepItem &it)
+__host__ __device__ __forceinline__ bool vs_single(const SweepItem &it)
 {
     return it.num_items == 0 && it.blk_end - it.blk_begin <= kVsTiles && vs_item_values(it) <= kVsVals;
 }
@@ -1123,6 +1125,62 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
 }
 
 }  // namespace
+
+// Which kernel bmsp_spmv launches for (A, variant) -- the launcher's own decisions, in its order -- and the bytes that kernel's layout
+// must move per launch ("compulsory": every array it reads or writes, once; counted from the plan, not estimated):
+//   value-stream, position cache: items (32 B) + keys (8 B per tile) + for items that are NOT a single batch the next-offset word of
+//     every tile (8 B: the 4 bytes read sit in an 8-byte stride) + entries (2 B) and values per stored value + x + y + carry slots;
+//   value-stream, in-kernel decode: items + keys, bitmaps, offsets (24 B per tile) + values + x + y;
+//   row-group / block-row kernels: block-row pointer + 24 B per tile + values + x + y;   sweep: items + 24 B per tile + values + x + y.
+// format_bytes is SURVEY 8(d)'s figure for the bmSparse layout whatever the kernel reads: 24 B per tile + values + row pointer + x + y.
+void spmv_launch_info(bmsp_matrix_s *A, int variant, hipStream_t st, char *kernel, size_t kernel_cap, int64_t *compulsory, int64_t *format_bytes)
+{
+    if (A->transposed) fail(BMSP_ERR_INVALID, "SpMV needs a matrix built with transposed=0");
+    ensure_rowptr(A, st);
+    const int64_t es = (int64_t)dtype_size(A->dtype), as = A->dtype == BMSP_F64 ? 8 : 4;
+    const int64_t nbr = A->num_block_rows(), nb = A->block_num, nv = A->nnz;
+    const int64_t xy = es * A->num_cols + as * A->num_rows;
+    const int64_t fmt = 24 * nb + es * nv + 4 * (nbr + 1) + xy;
+    if (format_bytes) *format_bytes = fmt;
+    const char *name = "";
+    int64_t bytes = fmt;
+    const bool wide = (size_t)A->values_extent() * (size_t)es >= (1ull << 32) || (size_t)A->num_cols * (size_t)es >= (1ull << 32);
+    if (nbr == 0) { name = "none (empty matrix)"; bytes = 0; }
+    else if (variant == BMSP_SPMV_BATCHED || wide) name = "spmv_blockrow_kernel<64 lanes per block-row>";
+    else if (variant == 2) name = "spmv_blockrow_kernel<8 lanes per block-row>";
+    else {
+        build_plan(A, st);
+        const bool dense_tiles = nb > 0 && nv >= 16 * nb;
+        if ((variant == 3 || (variant == BMSP_SPMV_DEFAULT && dense_tiles && A->spmv_plan_long == 0 && !getenv("BMSP_SPMV_NO_ROWGROUP"))) && pool_owns(A->values)) {
+            name = "spmv_rowgroup_kernel";
+        } else {
+            const int64_t n_items = A->spmv_num_chunks;
+            if (vstream_eligible(A)) {
+                build_pos_cache(A, st);
+                const bool cached = A->spmv_pos != nullptr;
+                const char *re = getenv("BMSP_SPMV_RED");
+                const int red = re ? atoi(re) : (nv < 2 * nb ? kAtomic : kSorted);
+                name = cached ? (red == kAtomic ? "spmv_vstream_kernel<kCached, kAtomic>" : "spmv_vstream_kernel<kCached, kSorted>")
+                              : (red == kAtomic ? "spmv_vstream_kernel<kDecode, kAtomic>" : "spmv_vstream_kernel<kDecode, kSorted>");
+                std::vector<SweepItem> items((size_t)n_items);
+                if (n_items) BMSP_HIP(hipMemcpyAsync(items.data(), plan_items(A), sizeof(SweepItem) * (size_t)n_items, hipMemcpyDeviceToHost, st));
+                BMSP_HIP(hipStreamSynchronize(st));
+                int64_t multi_tiles = 0, long_items = 0;
+                for (const SweepItem &it : items) {
+                    if (!vs_single(it)) multi_tiles += (int64_t)(it.blk_end - it.blk_begin);
+                    if (it.num_items) long_items++;
+                }
+                bytes = 32 * n_items + xy + 64 * long_items + es * nv;
+                bytes += cached ? 8 * nb + 8 * multi_tiles + 2 * nv : 24 * nb;
+            } else {
+                name = A->spmv_full_tiles * 4 >= nb ? "spmv_sweep_kernel<FULL>" : "spmv_sweep_kernel";
+                bytes = 32 * n_items + 24 * nb + es * nv + xy;
+            }
+        }
+    }
+    if (kernel && kernel_cap) snprintf(kernel, kernel_cap, "%s", name);
+    if (compulsory) *compulsory = bytes;
+}
 
 void prepare_spmv(bmsp_matrix_s *A, hipStream_t st)
 {

@@ -27,7 +27,7 @@ SYMBOLS = [
     "bmsp_event_create", "bmsp_event_record", "bmsp_event_elapsed_ms", "bmsp_event_destroy",
     "bmsp_matrix_from_mtx", "bmsp_matrix_from_coo", "bmsp_matrix_from_coo_device", "bmsp_matrix_from_arrays",
     "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_prepare", "bmsp_matrix_invalidate", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
-    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmm", "bmsp_spgemm", "bmsp_selftest_mfma_layout", "bmsp_segsort_u64",
+    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmv_launch_info", "bmsp_spmm", "bmsp_spgemm", "bmsp_selftest_mfma_layout", "bmsp_selftest_mfma_f32_chain", "bmsp_segsort_u64",
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
     "bmsp_comm_unique_id", "bmsp_comm_init", "bmsp_comm_init_from_env", "bmsp_comm_init_loopback", "bmsp_shard_layout", "bmsp_shard_row_slices", "bmsp_comm_info", "bmsp_comm_free", "bmsp_spgemm_sharded", "bmsp_spmv_sharded",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
@@ -44,11 +44,11 @@ class BmspError(RuntimeError):
 class SpgemmStats(C.Structure):
     _fields_ = [("task_list_size", C.c_int64), ("bmp_reduction", C.c_int64), ("surviving_tasks", C.c_int64),
                 ("c_blocks", C.c_int64), ("c_nnz", C.c_int64), ("t_us", C.c_double * 10),
-                ("sort_path", C.c_int), ("mac_kernel", C.c_int)]
+                ("sort_path", C.c_int), ("mac_kernel", C.c_int), ("mac_variant", C.c_int), ("reserved", C.c_int)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k in ("task_list_size", "bmp_reduction", "surviving_tasks", "c_blocks", "c_nnz",
-                                           "sort_path", "mac_kernel")}
+                                           "sort_path", "mac_kernel", "mac_variant")}
         d["t_us"] = list(self.t_us)
         return d
 
@@ -108,8 +108,10 @@ def lib():
         L.bmsp_matrix_compare.argtypes = [vp, i64, vp, vp, vp, p(C.c_double), p(i64)]
         L.bmsp_spmv.argtypes = [vp, vp, vp, i, vp]
         L.bmsp_spmm.argtypes = [vp, vp, i64, vp, i64, i, vp]
+        L.bmsp_spmv_launch_info.argtypes = [vp, i, C.c_char_p, C.c_size_t, p(i64), p(i64)]
         L.bmsp_spgemm.argtypes = [vp, vp, p(vp), i, i, i, vp, p(SpgemmStats)]
         L.bmsp_selftest_mfma_layout.argtypes = [p(i)]
+        L.bmsp_selftest_mfma_f32_chain.argtypes = [p(i)]
         L.bmsp_segsort_u64.argtypes = [vp, vp, i, i64, vp, i64, vp]
         L.bmsp_partition_rows.argtypes = [vp, vp, i, vp]
         L.bmsp_matrix_row_panel.argtypes = [vp, i64, i64, p(vp)]
@@ -403,6 +405,14 @@ def spmv(A, v, u=None, batched=False, stream=None):
         u = DeviceArray(i["num_rows"], OUT_DTYPE[i["dtype"]])
     check(lib().bmsp_spmv(A.h, v.ptr, u.ptr, SPMV_BATCHED if batched else SPMV_DEFAULT, stream))
     return u
+
+
+def spmv_launch_info(A, variant=0):
+    """{"kernel", "compulsory_bytes", "format_bytes"} of the launch bmsp_spmv would make for (A, variant)."""
+    name = C.create_string_buffer(128)
+    cb, fb = C.c_int64(), C.c_int64()
+    check(lib().bmsp_spmv_launch_info(A.h, int(variant), name, 128, C.byref(cb), C.byref(fb)))
+    return {"kernel": name.value.decode(), "compulsory_bytes": cb.value, "format_bytes": fb.value}
 
 
 def spmm(A, X, k, Y=None, ldx=None, ldy=None, stream=None):

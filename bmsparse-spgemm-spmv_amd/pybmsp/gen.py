@@ -33,14 +33,25 @@ def _merge(n_rows, n_cols, r, c, v):
 
 
 def banded(n, half_bw, seed=1):
-    """entries at |i-j| <= half_bw, values U(-1,1)."""
-    i = np.repeat(np.arange(n, dtype=np.int64), 2 * half_bw + 1)
-    j = i + np.tile(np.arange(-half_bw, half_bw + 1, dtype=np.int64), n)
-    ok = (j >= 0) & (j < n)
-    i, j = i[ok], j[ok]
-    ctr = (np.uint64(seed) << np.uint64(40)) + (i.astype(np.uint64) * np.uint64(2 * half_bw + 1) + (j - i + half_bw).astype(np.uint64))
-    v = 2.0 * uniform01(ctr) - 1.0
-    return n, n, i.astype(np.int32), j.astype(np.int32), v
+    """entries at |i-j| <= half_bw, values U(-1,1).  Generated in row chunks (the 75 M-entry ceiling case of bench.py would otherwise
+    hold several 64-bit temporaries of its full length); the counter of entry (i, j) is its index in the n x (2 half_bw + 1) grid."""
+    w = 2 * half_bw + 1
+    rows, cols, vals = [], [], []
+    step = max(1, (1 << 23) // w)
+    offs = np.arange(-half_bw, half_bw + 1, dtype=np.int32)
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        i = np.repeat(np.arange(r0, r1, dtype=np.int32), w)
+        j = i + np.tile(offs, r1 - r0)
+        ok = (j >= 0) & (j < n)
+        flat = np.arange(np.uint64(r0) * np.uint64(w), np.uint64(r1) * np.uint64(w), dtype=np.uint64)
+        if not ok.all():
+            i, j, flat = i[ok], j[ok], flat[ok]
+        rows.append(i); cols.append(j)
+        vals.append(2.0 * uniform01((np.uint64(seed) << np.uint64(40)) + flat) - 1.0)
+    if not rows:
+        return n, n, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0)
+    return n, n, np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
 
 
 def rmat(scale, edge_factor, a=0.57, b=0.19, c=0.19, seed=1, add_identity=True, chunk=1 << 22):

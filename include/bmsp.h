@@ -167,6 +167,13 @@ int bmsp_matrix_compare_device(bmsp_matrix_t m, int64_t nnz, const int *d_rows, 
  * SAME handle must not be in flight on different streams (different handles may). */
 int bmsp_spmv(bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *stream);
 
+/* What bmsp_spmv(A, ..., variant, ...) launches and what that launch must move (the measurement contract of SURVEY 8(d): "if the build
+ * stores a more compact internal layout, use that layout's compulsory bytes"): kernel_name receives the name of the kernel the launcher
+ * picks for this matrix (the cached plan and position cache are built if they are not yet), *compulsory_bytes the bytes of every array
+ * that kernel reads or writes, each once, counted from the plan; *format_bytes the layout-independent figure 24 B per block + values +
+ * block-row pointer + x + y.  Reporting only: no reference line to replace (the reference prints a time, src/bmSparse_SPMV.cu:306). */
+int bmsp_spmv_launch_info(bmsp_matrix_t A, int variant, char *kernel_name, size_t kernel_name_cap, int64_t *compulsory_bytes, int64_t *format_bytes);
+
 /* SURVEY 8(f)3 -- Y = A * X for k vectors at once (what the reference's unfinished `batched` path points at,
  * src/bmSparse_SPMV.cu:84-150,191).  X is row-major num_cols x k with leading dimension ldx (elements of A's dtype),
  * Y row-major num_rows x k with leading dimension ldy (float, double for F64): one pass over A's tiles for all k. */
@@ -184,7 +191,15 @@ typedef struct {
                                 [6]=T_6 [7]=T_7 [9]=T_9 ; [0]=whole call ("Toda F"); [8]=segmented sort only */
     int sort_path;           /* 0 = global radix sort (reference: thrust::sort), 1 = segmented sort */
     int mac_kernel;          /* which block-MAC kernel ran (see tc_version) */
+    int mac_variant;         /* which implementation of it: BMSP_MAC_* below */
+    int reserved;
 } bmsp_spgemm_stats;
+/* implementations behind one tc_version (the launcher picks by the product's shape; all give the tc_version's numerics) */
+#define BMSP_MAC_DEFAULT 0 /* the only kernel of that tc_version (V15 vector-ALU kernels, K = 16 MFMA kernels) */
+#define BMSP_MAC_STAGED 1  /* tc 4: K = 32 MFMA, operands staged through LDS per task (sparse task lists) */
+#define BMSP_MAC_DIRECT 2  /* tc 4: K = 32 MFMA, operand lines loaded per task straight into the MFMA lanes */
+#define BMSP_MAC_STRIP 3   /* tc 4: K = 32 MFMA, two block-rows of C per wave, A tiles register-resident, B tiles loaded once per strip */
+#define BMSP_MAC_F32MFMA 4 /* tc 5, fp32: V15's fmaf chain on v_mfma_f32_16x16x4_f32 */
 
 /* sort modes = the reference's `segmented` argument (src/bmSparse_SPGEMM.cu:963-1016):
  * 0 = global sort below BMSP_SORT_BORDER surviving tasks, segmented sort above; 1 = always segmented;
@@ -211,6 +226,11 @@ int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, in
  * loop.  *mismatches = number of wrong elements (0 on gfx950).  The reference's analogue is the fragment-layout assumption of
  * multiplyV12..V14 (src/bmSparse_SPGEMM.cu:548-552), which it never checks. */
 int bmsp_selftest_mfma_layout(int *mismatches);
+/* Hardware self test of the ACCUMULATION ORDER of v_mfma_f32_16x16x4_f32: D = C + A * B on random fp32 operands against the host chain
+ * fmaf(a_k, b_k, sum) for k ascending -- the order of multiplyV15<float, float> (src/bmSparse_SPGEMM.cu:269-273 as nvcc contracts it).
+ * *mismatches = number of result elements that differ in any bit.  With 0 the fp32 product (tc_version 5) runs its block-MAC on the
+ * matrix cores (BMSP_MAC_F32MFMA) with values bit-identical to the vector-ALU kernel; otherwise it stays on the vector ALU. */
+int bmsp_selftest_mfma_f32_chain(int *mismatches);
 
 /* bb_segsort<K,T>(keys, vals, n, segs, length)  -- include/bb_segsort-master/bb_segsort.h:35-192,
  * instantiated by the reference with K = uint64_t, T = 16-byte task_list_elem (src/bmSparse_SPGEMM.cu:1010).

@@ -547,6 +547,143 @@ def test_mfma32_block_mac_paths(oracle, bmsp, monkeypatch, case, b_dense, quota)
         np.testing.assert_allclose(vn, vo, rtol=2e-3, atol=1e-5)
 
 
+def test_mfma_f32_accumulation_order(bmsp):
+    """v_mfma_f32_16x16x4_f32 accumulates its four k as the ascending fmaf chain (checked on the hardware against a host fmaf chain on
+    random operands of mixed magnitude): the property the fp32 matrix-core block-MAC (BMSP_MAC_F32MFMA) rests on."""
+    import ctypes as C
+    bad = C.c_int(-1)
+    bmsp.check(bmsp.lib().bmsp_selftest_mfma_f32_chain(C.byref(bad)))
+    assert bad.value == 0
+
+
+@pytest.mark.parametrize("quota", ["64", ""])
+@pytest.mark.parametrize("case", ["rmat", "banded_full", "hub_c_blocks", "rect_ragged", "fem", "cancel"])
+def test_f32_mfma_block_mac(oracle, bmsp, monkeypatch, case, quota):
+    """tc_version 5 on fp32 operands through block_mac_f32_mfma_kernel (forced on every task-count profile, default and smallest wave
+    quota): V15's numerics -- the values must equal the oracle's k-ascending fmaf chain BIT FOR BIT on random fp32 values, and the
+    vector-ALU kernel's on the same operands; `cancel` has sums that end in +0 / -0 and C tiles of unequal task counts in one pair."""
+    from pybmsp import gen
+    monkeypatch.setenv("BMSP_MAC_F32MFMA", "1")
+    if quota:
+        monkeypatch.setenv("BMSP_MAC_QUOTA", quota)
+    if case == "rmat":
+        n, _, r, c, v = gen.rmat(11, 8)
+        A = Bc = (n, n, r, c, v)
+    elif case == "banded_full":
+        n, _, r, c, v = gen.banded(515, 20)
+        A = Bc = (n, n, r, c, v)
+    elif case == "hub_c_blocks":
+        nk = 8 * 300
+        r = np.repeat(np.arange(16), nk); c = np.tile(np.arange(nk), 16)
+        A = (16, nk, r, c, np.sin(r * 7.0 + c))
+        Bc = (nk, 16, c, r, np.cos(c * 3.0 + r))
+    elif case == "rect_ragged":
+        _, _, r1, c1, v1 = gen.random_coo(203, 77, 2500, seed=5)
+        _, _, r2, c2, v2 = gen.random_coo(77, 331, 3000, seed=6)
+        A, Bc = (203, 77, r1, c1, v1), (77, 331, r2, c2, v2)
+    elif case == "fem":
+        n, _, r, c, v = gen.fem_like(12, "27pt")
+        A = Bc = (n, n, r, c, v)
+    else:
+        # rows of +-1 against columns of +-1: exact cancellations (sums that pass through and end in zero), next to longer task lists
+        n = 64
+        r = np.repeat(np.arange(n), n); c = np.tile(np.arange(n), n)
+        keep = ((r // 8 + c // 8) % 3 != 1) | (r // 8 == 2)
+        r, c = r[keep], c[keep]
+        A = (n, n, r, c, np.where((r + c) % 2 == 0, 1.0, -1.0))
+        Bc = (n, n, r, c, np.where((r * 3 + c) % 4 < 2, 1.0, -1.0) * np.where(r % 8 < 4, 1.0, -1.0))
+    st = check_spgemm(oracle, bmsp, A, Bc, 0, 0, 5)       # not the MFMA tolerance branch: fp32 + tc 5 compares bit for bit
+    assert st["mac_kernel"] == 5 and st["mac_variant"] == 4, st
+    a = bmsp.BmSpMatrix.from_coo(*A, dtype=0)
+    b = bmsp.BmSpMatrix.from_coo(*Bc, transposed=True, dtype=0)
+    new, _ = bmsp.spgemm(a, b, tc_version=5)
+    monkeypatch.setenv("BMSP_MAC_F32MFMA", "0")
+    old, sto = bmsp.spgemm(a, b, tc_version=5)
+    assert sto["mac_variant"] == 0
+    vo, vn = old.host_arrays()[3], new.host_arrays()[3]
+    np.testing.assert_array_equal(vo.view(np.uint32), vn.view(np.uint32))
+
+
+def _strip_case(gen, oracle, case):
+    """(A, B, exact) for test_strip_block_mac: shapes that walk every leg of block_mac_strip_kernel."""
+    if case == "banded64":          # 17 tiles per block-row, 33 C tiles: merged lists of 18 / 34, two windows, cursors carried across
+        n, _, r, c, v = gen.banded(1029, 64)
+        return (n, n, r, c, np.round(v * 8) / 8), None, False
+    if case == "banded_wide":       # 5 windows per strip, 17 k-groups, odd number of block-rows (the last strip is a single row)
+        n, _, r, c, v = gen.banded(8 * 71 + 3, 256)
+        return (n, n, r, c, np.round(v * 4) / 4), None, False
+    if case == "fem":               # sparse tiles, ~40 % of the candidate pairs dropped by the bitmap filter
+        n, _, r, c, v = gen.fem_like(12, "27pt")
+        return (n, n, r, c, np.round(v * 16) / 16), None, False
+    if case == "fem_int":           # the integer stencil: every path exact
+        n, _, r, c, v = gen.fem_like(10, "7pt", values="stencil")
+        return (n, n, r, c, v), None, True
+    if case == "rect_ragged":
+        _, _, r1, c1, v1 = gen.random_coo(203, 77, 2500, seed=5, integer=True)
+        _, _, r2, c2, v2 = gen.random_coo(77, 331, 3000, seed=6, integer=True)
+        return (203, 77, r1, c1, v1), (77, 331, r2, c2, v2), True
+    if case == "filtered_run":
+        # block-row 0 of A: tile (0, 0) with ONLY its column 0 stored, tile (0, 1) full.  B's block-row 0: 100 tiles whose ONLY stored
+        # row is 7 (every pair with A(0, 0) is dropped by the filter and none of their columns is a C column); B's block-row 1: tiles at
+        # block-columns 0 and 120.  The strip's C columns are {0, 120}: the scan of B's block-row 0 meets > 32 tiles inside the window
+        # that are not C columns (the refill loop), and must skip them all.
+        ra, ca, va = [], [], []
+        for i in range(8):
+            ra.append(i); ca.append(0); va.append(1.0 + i)
+            for k in range(8):
+                ra.append(i); ca.append(8 + k); va.append(float((i + 2 * k) % 5 - 2) or 1.0)
+        rb, cb, vb = [], [], []
+        for j in range(1, 101):
+            for cc in range(8):
+                rb.append(7); cb.append(8 * j + cc); vb.append(float(cc + 1))
+        for j in (0, 120):
+            for kk in range(8):
+                for cc in range(8):
+                    rb.append(8 + kk); cb.append(8 * j + cc); vb.append(float((kk * 3 + cc) % 7 - 3) or 2.0)
+        A = (13, 16, np.array(ra), np.array(ca), np.array(va))
+        B = (16, 8 * 121, np.array(rb), np.array(cb), np.array(vb))
+        return A, B, True
+    if case == "empty_strips":      # block-rows 2..5 of A hold nothing (strips without a C tile), the last block-row is ragged
+        n, _, r, c, v = gen.banded(100, 9)
+        keep = (r < 16) | (r >= 48)
+        return (n, n, r[keep], c[keep], np.round(v[keep] * 8) / 8), None, False
+    raise ValueError(case)
+
+
+@pytest.mark.parametrize("case", ["banded64", "banded_wide", "fem", "fem_int", "rect_ragged", "filtered_run", "empty_strips"])
+def test_strip_block_mac(oracle, bmsp, monkeypatch, case):
+    """block_mac_strip_kernel (tc_version 4, BMSP_MAC_STRIP): two block-rows of C per wave, k-groups of the merged column list of A,
+    windows of 32 merged C columns, B's block-rows walked by cursor -- forced on small inputs that cross every boundary of that
+    schedule, against the oracle's exact-product numerics (stage counters and C structure bit for bit, values exact on integer inputs
+    and within the stated fp16 tolerance otherwise); the task-list kernel of the same tc_version must agree on the same operands."""
+    from pybmsp import gen
+    A, Bc, exact = _strip_case(gen, oracle, case)
+    if Bc is None:
+        Bc = A
+    monkeypatch.setenv("BMSP_MAC_STRIP", "1")
+    st = check_spgemm(oracle, bmsp, A, Bc, 1, 0, 4, exact_expected=exact)
+    assert st["mac_kernel"] == 4 and st["mac_variant"] == 3, st
+    a = bmsp.BmSpMatrix.from_coo(*A, dtype=1)
+    b = bmsp.BmSpMatrix.from_coo(*Bc, transposed=True, dtype=1)
+    new, _ = bmsp.spgemm(a, b, tc_version=4)
+    monkeypatch.setenv("BMSP_MAC_STRIP", "0")
+    old, sto = bmsp.spgemm(a, b, tc_version=4)
+    assert sto["mac_variant"] in (1, 2)
+    vo, vn = old.host_arrays()[3], new.host_arrays()[3]
+    if exact:
+        np.testing.assert_array_equal(vo, vn)
+    else:
+        np.testing.assert_allclose(vn, vo, rtol=2e-3, atol=1e-5)
+    if case == "banded64":  # non-finite operand values: the launcher must keep the task-list kernels (a skipped pair would turn 0 * inf into NaN)
+        r, c, v = A[2], A[3], np.array(A[4], dtype=np.float64)
+        v[7] = 1e9  # rounds to +inf in fp16
+        a2 = bmsp.BmSpMatrix.from_coo(A[0], A[1], r, c, v, dtype=1)
+        b2 = bmsp.BmSpMatrix.from_coo(A[0], A[1], r, c, v, transposed=True, dtype=1)
+        monkeypatch.setenv("BMSP_MAC_STRIP", "1")
+        _, st2 = bmsp.spgemm(a2, b2, tc_version=4)
+        assert st2["mac_variant"] != 3
+
+
 @pytest.mark.parametrize("case", ["rmat", "banded", "filtered", "rect"])
 def test_spgemm_single_pass_expansion(oracle, bmsp, monkeypatch, case):
     """BMSP_EXPAND_LOOKBACK: T_3 + T_4 as one decoupled look-back pass (survivors written at the running prefix of the earlier tiles);

@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
 """experiment helper: SpGEMM stage times for the bench matrices.  usage: spgemm_stages.py [case-substring] [--quick]
-cases: fem (fp32 + fp16), cage, dense (banded hb 32), banded (hb 8), rmat16"""
+cases: fem (fp32 + fp16), cage, dense (banded hb 32), banded (hb 8), rmat16, ceiling (banded hb 256: 77.9 M tasks; only when named)"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bmsparse-spgemm-spmv_amd"))
 import numpy as np, pybmsp as B
 from pybmsp import gen
 cases = [("fem_like(47,27pt)", lambda: gen.fem_like(47, "27pt")), ("cage_like(130228)", lambda: gen.cage_like(130228)),
          ("dense banded(131072,32)", lambda: gen.banded(131072, 32)), ("banded(101492,8)", lambda: gen.banded(101492, 8)),
-         ("rmat16(16,8)", lambda: gen.rmat(16, 8))]
+         ("rmat16(16,8)", lambda: gen.rmat(16, 8)), ("ceiling banded(147456,256)", lambda: gen.banded(147456, 256))]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 quick = "--quick" in sys.argv
 fp32 = "--fp32" in sys.argv  # with --quick: the fp32 V15 configuration instead of the fp16 MFMA one
-if args: cases = [c for c in cases if args[0] in c[0]]
+cases = [c for c in cases if args[0] in c[0]] if args else cases[:-1]
 for name, mk in cases:
     n, _, r, c, v = mk()
     for dtype, tc in ((((B.F32, 5),) if fp32 else ((B.F16, 4),)) if quick else ((B.F32, 5), (B.F16, 5), (B.F16, 4))):

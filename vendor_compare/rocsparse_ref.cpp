@@ -69,6 +69,60 @@ extern "C" int vendor_csr_spmv(int m, int n, int64_t nnz, const int *ptr, const 
     return 0;
 }
 
+// the same product ROTATED over `copies` device-resident copies of the matrix (each with its own descriptor, preprocessed), so that a
+// sweep streams from HBM instead of the Infinity Cache: the protocol bench.py's headline `value` uses for the bmSparse sweep
+extern "C" int vendor_csr_spmv_rotated(int m, int n, int64_t nnz, const int *ptr, const int *col, const float *val, const float *x, int alg, int iters,
+                                       int copies, double *ms_per_spmv)
+{
+    rocsparse_handle h;
+    RSCK(rocsparse_create_handle(&h));
+    if (copies < 1) copies = 1;
+    std::vector<int *> dptr((size_t)copies), dcol((size_t)copies);
+    std::vector<float *> dval((size_t)copies), dy((size_t)copies);
+    std::vector<rocsparse_spmat_descr> A((size_t)copies);
+    std::vector<rocsparse_dnvec_descr> vy((size_t)copies);
+    std::vector<void *> buf((size_t)copies, nullptr);
+    float *dx;
+    if (upload(&dx, x, (size_t)n)) return 1;
+    rocsparse_dnvec_descr vx;
+    RSCK(rocsparse_create_dnvec_descr(&vx, n, dx, rocsparse_datatype_f32_r));
+    const float alpha = 1.f, beta = 0.f;
+    const rocsparse_spmv_alg a = alg == 1 ? rocsparse_spmv_alg_csr_adaptive : alg == 2 ? rocsparse_spmv_alg_csr_rowsplit : alg == 3 ? rocsparse_spmv_alg_csr_lrb
+                                                                                                                                       : rocsparse_spmv_alg_default;
+    size_t bytes = 0;
+    for (int c = 0; c < copies; c++) {
+        if (upload(&dptr[(size_t)c], ptr, (size_t)m + 1) || upload(&dcol[(size_t)c], col, (size_t)nnz) || upload(&dval[(size_t)c], val, (size_t)nnz)) return 1;
+        HIPCK(hipMalloc((void **)&dy[(size_t)c], (size_t)(m ? m : 1) * 4));
+        RSCK(rocsparse_create_csr_descr(&A[(size_t)c], m, n, nnz, dptr[(size_t)c], dcol[(size_t)c], dval[(size_t)c], rocsparse_indextype_i32, rocsparse_indextype_i32,
+                                        rocsparse_index_base_zero, rocsparse_datatype_f32_r));
+        RSCK(rocsparse_create_dnvec_descr(&vy[(size_t)c], m, dy[(size_t)c], rocsparse_datatype_f32_r));
+        RSCK(rocsparse_spmv(h, rocsparse_operation_none, &alpha, A[(size_t)c], vx, &beta, vy[(size_t)c], rocsparse_datatype_f32_r, a, rocsparse_spmv_stage_buffer_size, &bytes, nullptr));
+        HIPCK(hipMalloc(&buf[(size_t)c], bytes ? bytes : 4));
+        RSCK(rocsparse_spmv(h, rocsparse_operation_none, &alpha, A[(size_t)c], vx, &beta, vy[(size_t)c], rocsparse_datatype_f32_r, a, rocsparse_spmv_stage_preprocess, &bytes, buf[(size_t)c]));
+        RSCK(rocsparse_spmv(h, rocsparse_operation_none, &alpha, A[(size_t)c], vx, &beta, vy[(size_t)c], rocsparse_datatype_f32_r, a, rocsparse_spmv_stage_compute, &bytes, buf[(size_t)c]));
+    }
+    hipEvent_t e0, e1;
+    HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+    HIPCK(hipDeviceSynchronize());
+    HIPCK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) {
+        const size_t c = (size_t)(i % copies);
+        RSCK(rocsparse_spmv(h, rocsparse_operation_none, &alpha, A[c], vx, &beta, vy[c], rocsparse_datatype_f32_r, a, rocsparse_spmv_stage_compute, &bytes, buf[c]));
+    }
+    HIPCK(hipEventRecord(e1, 0)); HIPCK(hipEventSynchronize(e1));
+    float ms = 0; HIPCK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_spmv = ms / (iters > 0 ? iters : 1);
+    for (int c = 0; c < copies; c++) {
+        rocsparse_destroy_spmat_descr(A[(size_t)c]); rocsparse_destroy_dnvec_descr(vy[(size_t)c]);
+        hipFree(buf[(size_t)c]); hipFree(dptr[(size_t)c]); hipFree(dcol[(size_t)c]); hipFree(dval[(size_t)c]); hipFree(dy[(size_t)c]);
+    }
+    rocsparse_destroy_dnvec_descr(vx);
+    hipFree(dx);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    rocsparse_destroy_handle(h);
+    return 0;
+}
+
 // C = A B, fp32 CSR.  Every timed iteration runs the nnz stage and the compute stage (the full product with the C arrays and the
 // work buffer kept from the first call, i.e. what a pooled allocator gives); *first_ms includes the allocations.
 extern "C" int vendor_csr_spgemm(int m, int k, int n, int64_t nnzA, const int *ptrA, const int *colA, const float *valA, int64_t nnzB, const int *ptrB,
