@@ -390,7 +390,7 @@ SPGEMM_CASES = [
     ("ceiling", "dense-tile ceiling: banded(147456, half_bw=256), 65 full 8x8 tiles per block-row, 7.8e7 tasks, 32.8 per C tile", lambda g: g.banded(147456, 256), "F16", 4, None, "spgemm_ceiling"),
 ]
 MAC_VARIANT = {0: "default kernel of the tc_version", 1: "block_mac_mfma32_kernel (K = 32, LDS-staged)", 2: "block_mac_direct_kernel (K = 32, lines per task)",
-               3: "block_mac_strip_kernel (K = 32, two block-rows per wave, operand reuse)", 4: "block_mac_f32_mfma_kernel (v_mfma_f32_16x16x4_f32, V15 chain)"}
+               3: "block_mac_strip_kernel (K = 32, two block-rows per wave, operand reuse)", 4: "block_mac_f32_mfma_kernel (v_mfma_f32_16x16x4_f32, V15 chain, lane-ordered tile copies)"}
 
 
 def stage_bytes(st, sort_bits):

@@ -545,9 +545,16 @@ int launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *t
     g.c_bmps = C->bmps; g.c_offs = C->offsets; g.c_vals = (float *)C->values; g.c_size = cs;
     // equal task quotas per wave, a multiple of 64 (c_of_wave is indexed per 64 tasks); ~8 quotas per resident wave slot so
     // that hub tiles and uneven tiles-per-task do not leave a tail
+    // >= 4.6 tasks per C tile: the direct kernel (no LDS); sparser task lists keep the staged one (BMSP_MAC_DIRECT = 0 / 1 forces)
+    const char *de = getenv("BMSP_MAC_DIRECT");
+    const bool direct = b_dense && (de ? de[0] == '1' : 10 * n_tasks >= 46 * (uint64_t)cs);
     const char *qenv = getenv("BMSP_MAC_QUOTA");
     uint64_t quota = qenv ? (uint64_t)atoll(qenv) : (n_tasks + 32767) / 32768;
     quota = std::max<uint64_t>(256, (quota + 63) / 64 * 64);
+    // the direct kernel reads every operand line from the L2 or beyond: short quotas keep the resident waves of an XCD on few block-rows
+    // at a time, whose B tiles then meet in its L2 (FEM-like T_7: 584 us at 1024 tasks per wave, 574 at 768, 530 at 256, 526 at 128;
+    // dense ceiling 1590 -> 1429 us)
+    if (direct && !qenv) quota = 256;
     const uint64_t waves = (n_tasks + quota - 1) / quota;
     const uint32_t grid = (uint32_t)((waves + 3) / 4);
     g.quota = (uint32_t)quota;
@@ -559,9 +566,6 @@ int launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *t
     }
     const char *venv = getenv("BMSP_MAC_VARIANT");  // timing experiments: 4 = no store phase, 8 = no MFMA loop, 16 = no staging (wrong results)
     const int v = venv ? atoi(venv) : 0;
-    // >= 4.6 tasks per C tile: the direct kernel (no LDS); sparser task lists keep the staged one (BMSP_MAC_DIRECT = 0 / 1 forces)
-    const char *de = getenv("BMSP_MAC_DIRECT");
-    const bool direct = b_dense && (de ? de[0] == '1' : 10 * n_tasks >= 46 * (uint64_t)cs);
     const char *ue = getenv("BMSP_MAC_DIRECT_U");  // experiment switch: steps per pipeline block (1, 2, 4)
     const int du = ue ? atoi(ue) : 1;  // measured on MI355X (FEM-like / dense ceiling T_7, us): U = 1: 574 / 1631, 2: 640 / 1590, 4: 696 / 1596 -- the kernel is bound by the fabric
                                          // rate of its 128-byte line gathers (~11 TB/s), not by round trips, so deeper blocks only cost occupancy

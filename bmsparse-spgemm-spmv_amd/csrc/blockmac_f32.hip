@@ -255,15 +255,14 @@ bool mac_f32_mfma_usable(hipStream_t st)
 bool launch_mac_f32_mfma(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *task_begin, const uint32_t *c_of_wave, bmsp_matrix_s *A,
                          bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st)
 {
-    const char *force = getenv("BMSP_MAC_F32MFMA");  // 0 / 1: experiment and test switch
-    if (force && force[0] == '0') return false;
+    // Opt-in (BMSP_MAC_F32MFMA=1).  Measured on MI355X the kernel is bound by the 256 bytes it reads per operand tile and beats neither
+    // vector-ALU kernel: FEM-like product (3.7 values per tile) T_7 1.71 ms vs 1.62 ms for the element-gather kernel, full-tile banded
+    // 127 us vs 96 us for the dense-staged one (block-MAC log round 3).  Kept, with its parity tests, as the measured answer to
+    // "does the fp32 MFMA help V15".
+    const char *force = getenv("BMSP_MAC_F32MFMA");
+    if (!force || force[0] != '1') return false;
     if (A->dtype != BMSP_F32 || n_tasks >= (1ull << 29) || A->block_num >= (1ll << 24) || B->block_num >= (1ll << 24)) return false;
     const uint32_t cs = (uint32_t)C->block_num;
-    // below ~2 tasks per C tile most K slots of a pair stay empty and the vector-ALU kernel's group schedule wins; and the kernel reads
-    // 256 bytes per operand tile whatever the tile holds -- measured on the FEM-like product (3.7 values per tile: the copies are 17 x the
-    // matrix) it is bound by that traffic and no faster than the vector-ALU kernel's element gathers (1.71 vs 1.62 ms), so it is taken
-    // where tiles are at least a quarter full
-    if (!force && (2 * n_tasks < 3 * (uint64_t)cs || A->nnz < 16 * A->block_num || B->nnz < 16 * B->block_num)) return false;
     if (!mac_f32_mfma_usable(st)) return false;
     ensure_lane_tiles(A, st);
     ensure_lane_tiles(B, st);

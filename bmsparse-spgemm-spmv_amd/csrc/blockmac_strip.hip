@@ -125,8 +125,9 @@ struct ScanPre {
     uint32_t cur, end;
 };
 
-// NB = B lines (column pairs) a wave keeps in flight, OCC = waves per SIMD the register allocation is held to
-template <int NB, int OCC>
+// PAIRS = column pairs of a window (2 PAIRS C-tile columns of the strip, 4 PAIRS accumulator registers), NB = B lines (column pairs) a wave
+// requests together, OCC = waves per SIMD the register allocation is held to
+template <int PAIRS, int NB, int OCC>
 __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArgs g)
 {
     __shared__ StripLds lds_all[4];
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     const int q16 = lane & 15;                         // scan: tile q16 / q16 + 16 behind the cursor of k slot ks
     const int d_row = lane >> 5;                       // result: block-row of the strip this lane's D values belong to
     const uint32_t d_r0 = 4u * (uint32_t)((lane >> 4) & 1);  // first of its four tile rows
-    const uint32_t nG = (nK + 3) / 4, nW = (nJ + 31) / 32;
+    constexpr uint32_t SLOTS = 2u * PAIRS;  // C-tile columns of a window
+    const uint32_t nG = (nK + 3) / 4, nW = (nJ + SLOTS - 1) / SLOTS;
     if (nG == 0) return;  // (C tiles without an A tile cannot exist)
 
     // one (window, k-group) of the walk = an "item"; items are taken window by window, k-group by k-group
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     // tile index
     auto scan = [&](const Item &it, uint32_t tb, ScanPre &pre) {
         if (!it.on) return;
-        const uint32_t s0 = 32 * it.wi, ns = min(32u, nJ - s0);
+        const uint32_t s0 = SLOTS * it.wi, ns = min(SLOTS, nJ - s0);
         const uint32_t jlo = S.jj[s0], jhi = S.jj[s0 + ns - 1];
         const bool dense_win = jhi - jlo == ns - 1u;
         const uint32_t u = 4 * it.gi + (uint32_t)ks;
@@ -269,9 +271,9 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     scan(cur, 0u, pre);
     __builtin_amdgcn_wave_barrier();
     pre = request(nxt);
-    float4_t acc[16];
+    float4_t acc[PAIRS];
 #pragma unroll
-    for (int p = 0; p < 16; p++) acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < PAIRS; p++) acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
     uint32_t tb = 0;
     while (cur.on) {
         const uint32_t u = 4 * cur.gi + (uint32_t)ks;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
         // branches), then -- once per item -- the next item's scan, then the batch's MFMAs.
         bool scanned = false;
 #pragma unroll
-        for (int hb = 0; hb < 16 / NB; hb++) {
+        for (int hb = 0; hb < PAIRS / NB; hb++) {
             const uint32_t mb = (pm >> (NB * hb)) & ((1u << NB) - 1u);
             if (mb) {
                 half8_t fb[NB];
@@ -320,10 +322,10 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
         __builtin_amdgcn_wave_barrier();
         if (cur.gi + 1 == nG) {
             // ---- the window is complete: lane holds D[4 * (lane >> 4) + i][lane & 15] = rows d_r0 + i of C(row d_row, column 2p + half_sel) ----
-            const uint32_t s0 = 32 * cur.wi, ns = min(32u, nJ - s0);
+            const uint32_t s0 = SLOTS * cur.wi, ns = min(SLOTS, nJ - s0);
             const uint32_t crow0 = d_row ? c0e : c0b;
 #pragma unroll
-            for (int p = 0; p < 16; p++) {
+            for (int p = 0; p < PAIRS; p++) {
                 const uint32_t sl = 2u * (uint32_t)p + (uint32_t)half_sel;
                 const uint32_t crel = sl < ns ? (uint32_t)S.jc[s0 + sl][d_row] : 0xffffu;
                 if (crel != 0xffffu) {
@@ -376,8 +378,11 @@ bool mac_strip_eligible(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, ui
     ensure_row_stats(A, st);
     if (2 * A->max_row_blocks > kKCap) return false;
     if (!force) {
-        // the walk visits every candidate pair: it pays when most of them survive the filter and C tiles collect several tasks each
-        if (10 * n_tasks < 46 * (uint64_t)C->block_num || 2 * n_tasks < candidates) return false;
+        // The walk visits every candidate pair and pays a fixed price per (window, k-group) item: it wins where items are fat -- C tiles
+        // that collect many tasks from candidate pairs that nearly all survive (dense-tile ceiling: 32.8 tasks per C tile, 840 us against
+        // 1430 us for the direct kernel).  On the FEM-like product (14 tasks per C tile, 61 % of the pairs survive, 3 MFMAs per item) the
+        // direct kernel stays ahead (530 vs 640 us), so the bar sits between the two.
+        if (n_tasks < 20 * (uint64_t)C->block_num || 10 * n_tasks < 9 * candidates) return false;
     }
     ensure_row_stats(C, st);
     if (2 * C->max_row_blocks > kJCap) return false;
@@ -402,11 +407,12 @@ void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipS
     g.c_keys = C->keys; g.c_bmps = C->bmps; g.c_offs = C->offsets; g.c_rowptr = C->rowptr; g.c_vals = (float *)C->values;
     g.block_rows = (uint32_t)A->num_block_rows();
     const uint32_t strips = (g.block_rows + 1) / 2;
-    const char *ve = getenv("BMSP_STRIP_VARIANT");  // experiment switch: B lines in flight / waves per SIMD = 0: 8 / 3, 1: 4 / 3, 2: 16 / 2
-    const int v = ve ? atoi(ve) : 0;
-    if (v == 1) hipLaunchKernelGGL((block_mac_strip_kernel<4, 3>), dim3((strips + 3) / 4), dim3(kThreads), 0, st, g);
-    else if (v == 2) hipLaunchKernelGGL((block_mac_strip_kernel<16, 2>), dim3((strips + 3) / 4), dim3(kThreads), 0, st, g);
-    else hipLaunchKernelGGL((block_mac_strip_kernel<8, 3>), dim3((strips + 3) / 4), dim3(kThreads), 0, st, g);
+    // Measured on MI355X (T_7, us; dense-tile ceiling / FEM-like forced): 16 pairs per window, 8 lines requested together, 3 waves per SIMD
+    // 840 / 637; 16 lines together at 2 waves per SIMD 975 / 736, at 3 waves (28 spilled registers) 1580 / 878; 8-pair windows 881 / 662;
+    // one workgroup per strip (shared tables, windows dealt to the four waves, cursors re-seeded per window) 1058 / 692.
+    const dim3 grid((strips + 3) / 4);
+    if (getenv("BMSP_STRIP_WIDE")) hipLaunchKernelGGL((block_mac_strip_kernel<16, 16, 2>), grid, dim3(kThreads), 0, st, g);  // experiment switch
+    else hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3>), grid, dim3(kThreads), 0, st, g);
     BMSP_CHECK_LAUNCH();
 }
 

@@ -395,7 +395,7 @@ void invalidate_matrix(bmsp_matrix_s *m, int structure_changed)
     if (!structure_changed) return;
     pool_free(m->rowptr); m->rowptr = nullptr; m->rowptr_rows = 0; m->max_row_blocks = -1;
     pool_free(m->spmv_chunks); m->spmv_chunks = nullptr; m->spmv_num_chunks = 0; m->spmv_plan_long = 0; m->spmv_full_tiles = 0;
-    pool_free(m->spmv_pos); m->spmv_pos = nullptr; m->spmv_pos_base = 0; m->spmv_pos_count = 0; m->spmv_pos_tried = 0;
+    pool_free(m->spmv_pos); m->spmv_pos = nullptr; m->spmv_tinfo = nullptr; m->spmv_eoff = nullptr; m->spmv_pos_base = 0; m->spmv_pos_count = 0; m->spmv_pos_tried = 0;
     pool_free(m->block_meta); m->block_meta = nullptr;
     free_matrix(m->shard_view); m->shard_view = nullptr; m->shard_world = 0; m->shard_rank = 0; m->shard_bounds.clear();
 }
@@ -463,8 +463,8 @@ void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st)
     if (m->dtype == BMSP_F16 && m->block_num < (1ll << 25) && (!m->transposed || mac_mfma32_b_dense(m))) ensure_dense_tiles(m, st);
     // V15 block-MAC (tc_version 5): fp32 operands with tiles at least a quarter full are staged from a dense copy too (256 B per block)
     if (m->dtype == BMSP_F32 && m->nnz >= 16 * m->block_num && (uint64_t)m->block_num * 256 <= (4ull << 30)) ensure_dense_tiles(m, st);
-    // fp32 MFMA block-MAC (tc_version 5 where the hardware self test passed): the tiles in MFMA lane order (256 B per block)
-    if (m->dtype == BMSP_F32 && m->block_num < (1ll << 24) && m->nnz >= 16 * m->block_num && mac_f32_mfma_usable(st)) ensure_lane_tiles(m, st);
+    // fp32 MFMA block-MAC (opt-in, BMSP_MAC_F32MFMA=1): the tiles in MFMA lane order (256 B per block)
+    if (m->dtype == BMSP_F32 && getenv("BMSP_MAC_F32MFMA") && mac_f32_mfma_usable(st)) ensure_lane_tiles(m, st);
 }
 
 bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, const int *d_rows, const int *d_cols,

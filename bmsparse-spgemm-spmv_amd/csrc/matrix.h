@@ -29,6 +29,8 @@ struct bmsp_matrix_s {
     size_t spmv_plan_off_cnt = 0, spmv_plan_off_carry = 0;
     // position cache of the value-stream SpMV: one 16-bit {tile slot in its batch, position in the tile} entry per stored value
     uint16_t *spmv_pos = nullptr;
+    uint32_t *spmv_tinfo = nullptr;  // same allocation: per tile {block column, block-row inside its item's window} (the value-stream kernel's slot word)
+    uint16_t *spmv_eoff = nullptr;   // same allocation: per tile, end of its values relative to its item's first value
     int64_t spmv_pos_base = 0, spmv_pos_count = 0;
     int spmv_pos_tried = 0;
     // (bitmap, value offset) of every block as one 16-byte record, for kernels that gather both (block-MAC): built lazily

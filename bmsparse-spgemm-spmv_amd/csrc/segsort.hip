@@ -15,6 +15,7 @@
 #include "matrix.h"
 #include "prims.hip.h"
 #include <cstdlib>
+#include <utility>
 
 namespace bmsp {
 namespace {
@@ -509,18 +510,182 @@ __global__ __launch_bounds__(512) void segsort_tasks_block_kernel(uint64_t *__re
     sort_task_segment<W, 512, true, kTaskBlockIdxBits>(s_a, keys, perm, lo, (uint32_t)(hi - lo), 1024u, col_mask, threadIdx.x);
 }
 
-template <typename W>
-bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *segs, uint32_t nseg, int jbits, hipStream_t st)
+// ---- segments beyond a wave's / workgroup's capacity: pieces + merge passes --------------------------------------------------------
+// bb_segsort sorts segments above 2048 with a block sort of 2048-key pieces followed by doubling merge passes (kern_block_sort /
+// kern_block_merge, include/bb_segsort-master/bb_comput_l.h:1155-1284).  Same plan here: a long segment is cut into pieces of at most
+// `cap` words, the pieces go through the register / LDS sorts above like ordinary segments, then ceil(log2(pieces)) merge passes join
+// them.  A merge pass works on output tiles of kMergeTile elements (merge path: two binary searches on the tile's diagonals find the
+// input ranges, the ranges meet in LDS, every thread merges four outputs); what is merged is the composite word (column << 32) | source
+// position, which is unique, so the result is the STABLE order whatever the merge does with ties.  Before round 3 one long segment sent
+// the whole call to the global radix sort.
+constexpr uint32_t kMergeTile = 1024;
+
+struct PiecesIn {  // pieces a segment is cut into (1 for segments that fit)
+    SegClassify c;
+    uint32_t cap;
+    __device__ uint32_t operator()(uint64_t s) const { return s < c.nseg ? max(1u, (c.len(s) + cap - 1u) / cap) : 0u; }
+};
+struct PiecesOut {
+    SegClassify c;
+    uint32_t cap;
+    int *segs2;
+    uint32_t *total, *max_len, *long_elems;
+    __device__ void operator()(uint64_t s, uint32_t ex, uint32_t cnt) const
+    {
+        if (s == c.nseg) { *total = ex; return; }
+        const uint32_t lo = (uint32_t)c.segs[s];
+        for (uint32_t p = 0; p < cnt; p++) segs2[ex + p] = (int)(lo + p * cap);
+        if (cnt > 1) { atomicMax(max_len, c.len(s)); atomicAdd(long_elems, c.len(s)); }
+    }
+};
+struct MergeWork {
+    uint32_t lo, len, tile;
+};
+struct MergeTilesIn {  // output tiles of the LONG segments (the others are not touched by the merge passes)
+    SegClassify c;
+    uint32_t cap;
+    __device__ uint32_t operator()(uint64_t s) const
+    {
+        if (s >= c.nseg) return 0u;
+        const uint32_t l = c.len(s);
+        return l > cap ? (l + kMergeTile - 1u) / kMergeTile : 0u;
+    }
+};
+struct MergeTilesOut {
+    SegClassify c;
+    MergeWork *work;
+    uint32_t *total;
+    __device__ void operator()(uint64_t s, uint32_t ex, uint32_t cnt) const
+    {
+        if (s == c.nseg) { *total = ex; return; }
+        for (uint32_t t = 0; t < cnt; t++) work[ex + t] = MergeWork{(uint32_t)c.segs[s], c.len(s), t};
+    }
+};
+
+// one pass: runs of length R inside every long segment are merged pairwise; (src) -> (dst)
+__global__ __launch_bounds__(kThreads) void merge_pass_kernel(const uint64_t *__restrict__ src_keys, const uint32_t *__restrict__ src_perm,
+                                                              uint64_t *__restrict__ dst_keys, uint32_t *__restrict__ dst_perm,
+                                                              const MergeWork *__restrict__ work, uint32_t R, uint64_t col_mask)
 {
+    __shared__ uint64_t buf[kMergeTile];
+    __shared__ uint32_t split[2];
+    const MergeWork w = work[blockIdx.x];
+    const uint32_t o0 = w.tile * kMergeTile, o1 = min(o0 + kMergeTile, w.len);
+    const uint32_t base = o0 / (2u * R) * (2u * R);
+    const uint32_t a_len = min(R, w.len - base), b_len = min(R, w.len - base - a_len);
+    const uint64_t A = (uint64_t)w.lo + base, Bq = A + a_len;
+    auto comp = [&](uint64_t i) { return ((src_keys[i] & col_mask) << 32) | (uint64_t)src_perm[i]; };
+    // number of A elements among the first d outputs of the pair
+    auto path = [&](uint32_t d) {
+        uint32_t lo = d > b_len ? d - b_len : 0u, hi = min(d, a_len);
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (comp(A + mid) < comp(Bq + (d - 1u - mid))) lo = mid + 1u;
+            else hi = mid;
+        }
+        return lo;
+    };
+    if (threadIdx.x == 0) split[0] = path(o0 - base);
+    if (threadIdx.x == 64) split[1] = path(o1 - base);
+    __syncthreads();
+    const uint32_t a0 = split[0], a1 = split[1];
+    const uint32_t b0 = (o0 - base) - a0, n_out = o1 - o0, na = a1 - a0, nb = n_out - na;
+    for (uint32_t e = threadIdx.x; e < n_out; e += kThreads) buf[e] = e < na ? comp(A + a0 + e) : comp(Bq + b0 + (e - na));
+    const uint64_t row_part = src_keys[w.lo] & ~col_mask;
+    __syncthreads();
+    // thread t: outputs 4 t .. 4 t + 3 of the tile
+    const uint32_t d = min(4u * threadIdx.x, n_out);
+    uint32_t lo = d > nb ? d - nb : 0u, hi = min(d, na);
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (buf[mid] < buf[na + (d - 1u - mid)]) lo = mid + 1u;
+        else hi = mid;
+    }
+    uint32_t ia = lo, ib = d - lo;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t o = d + (uint32_t)k;
+        if (o < n_out) {
+            const bool take_a = ib >= nb || (ia < na && buf[ia] < buf[na + ib]);
+            const uint64_t c = take_a ? buf[ia] : buf[na + ib];
+            ia += take_a ? 1u : 0u;
+            ib += take_a ? 0u : 1u;
+            dst_keys[(uint64_t)w.lo + o0 + o] = row_part | (c >> 32);
+            dst_perm[(uint64_t)w.lo + o0 + o] = (uint32_t)c;
+        }
+    }
+}
+
+struct CopyKeyPerm {
+    const uint64_t *ks;
+    const uint32_t *ps;
+    uint64_t *kd;
+    uint32_t *pd;
+    __device__ void operator()(uint64_t i) const { kd[i] = ks[i]; pd[i] = ps[i]; }
+};
+
+// sorts the segments of (keys, perm) -- keys in place, perm[i] = source position of the element now at i.  `alt_keys` is a scratch array
+// of n keys the caller provides (the ping-pong partner), `perm_alt` an empty buffer the merge passes allocate.  Returns false when the
+// call is not handled (nothing modified).  *in_alt = true: the result sits in (alt_keys, perm_alt) -- an odd number of merge passes over a
+// list in which EVERY segment was long: nothing has to be copied home, the caller flips its buffers.
+template <typename W>
+bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *segs, uint32_t nseg, int jbits, hipStream_t st, uint64_t *alt_keys = nullptr,
+                       DevBuf<uint32_t> *perm_alt = nullptr, bool *in_alt = nullptr)
+{
+    if (in_alt) *in_alt = false;
     if (nseg >= (1u << 21)) return false;
-    SegClassify cls{segs, nseg, n, sizeof(W) == 4 ? 2 * kTaskWaveMax : kTaskWaveMax};  // 32-bit words: a wave holds a 4096-word segment in registers
+    const uint32_t cap = sizeof(W) == 4 ? 2 * kTaskWaveMax : kTaskWaveMax;  // 32-bit words: a wave holds a 4096-word segment in registers
+    SegClassify cls{segs, nseg, n, cap};
     DevBuf<uint32_t> wave_list(nseg), block_list(nseg);
     HostScalar<uint64_t> tot;
     device_exclusive_scan<uint64_t>(cls, SegLists{cls, wave_list.p, block_list.p, tot.dev(), perm}, (uint64_t)nseg + 1, st);
     const uint64_t t = tot.wait(st);
     const uint32_t n_wave = (uint32_t)(t & 0x1fffffu), n_block = (uint32_t)((t >> 21) & 0x1fffffu), n_long = (uint32_t)(t >> 42);
-    if (n_long) return false;
     const uint64_t col_mask = (1ull << jbits) - 1ull;
+    if (n_long) {
+        if (!perm_alt || !alt_keys || getenv("BMSP_SEGSORT_NO_MERGE")) return false;
+        // 1. pieces of at most `cap` words; the pieces are sorted like ordinary segments
+        const uint64_t max_pieces = (uint64_t)nseg + n / cap + 1;
+        if (max_pieces >= (1u << 21)) return false;
+        DevBuf<int> segs2(max_pieces);
+        DevBuf<uint32_t> scal(3);
+        BMSP_HIP(hipMemsetAsync(scal.p, 0, 12, st));
+        device_exclusive_scan<uint32_t>(PiecesIn{cls, cap}, PiecesOut{cls, cap, segs2.p, scal.p, scal.p + 1, scal.p + 2}, (uint64_t)nseg + 1, st);
+        uint32_t hs[3];
+        BMSP_HIP(hipMemcpyAsync(hs, scal.p, 12, hipMemcpyDeviceToHost, st));
+        BMSP_HIP(hipStreamSynchronize(st));
+        const uint32_t nseg2 = hs[0], max_len = hs[1];
+        const bool all_long = (uint64_t)hs[2] == n;
+        if (!segsort_tasks_lds<W>(keys, perm, n, segs2.p, nseg2, jbits, st)) return false;
+        // 2. output tiles of the long segments
+        SegClassify all{segs, nseg, n, cap};
+        DevBuf<uint32_t> wtot(1);
+        const uint64_t max_tiles = n / kMergeTile + (uint64_t)n_long + 1;
+        DevBuf<MergeWork> work(max_tiles);
+        device_exclusive_scan<uint32_t>(MergeTilesIn{all, cap}, MergeTilesOut{all, work.p, wtot.p}, (uint64_t)nseg + 1, st);
+        const uint32_t n_work = read_back(wtot.p, st);
+        // 3. merge passes, ping-pong between (keys, perm) and (alt_keys, perm2); an odd number of passes ends in the scratch pair, which is
+        //    copied back (elements of short segments never leave the primary pair)
+        perm_alt->alloc(n);
+        uint64_t *ks = keys, *kd = alt_keys;
+        uint32_t *ps = perm, *pd = perm_alt->p;
+        int passes = 0;
+        for (uint64_t R = cap; R < max_len; R *= 2) {
+            hipLaunchKernelGGL(merge_pass_kernel, dim3(n_work), dim3(kThreads), 0, st, ks, ps, kd, pd, work.p, (uint32_t)R, col_mask);
+            BMSP_CHECK_LAUNCH();
+            std::swap(ks, kd); std::swap(ps, pd);
+            passes++;
+        }
+        if ((passes & 1) && all_long && in_alt) {
+            *in_alt = true;  // every element went through the passes: the scratch pair holds the whole result
+        } else if (passes & 1) {
+            // the long segments' result sits in (alt_keys, perm_alt): bring it home tile by tile (a "merge" of runs as long as the segment copies)
+            hipLaunchKernelGGL(merge_pass_kernel, dim3(n_work), dim3(kThreads), 0, st, ks, ps, kd, pd, work.p, 0x40000000u, col_mask);
+            BMSP_CHECK_LAUNCH();
+        }
+        BMSP_HIP(hipStreamSynchronize(st));  // the work list goes back to the pool
+        return true;
+    }
     if (n_wave) {
         hipLaunchKernelGGL((segsort_tasks_wave_kernel<W>), dim3((n_wave + 3) / 4), dim3(kThreads), 0, st, keys, perm, segs, nseg, n, wave_list.p, n_wave, col_mask);
         BMSP_CHECK_LAUNCH();
@@ -564,11 +729,15 @@ bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals,
     HostScalar<uint32_t> cnt;
     device_exclusive_scan<uint32_t>(RunHead{keys.cur, n, jbits}, EmitRunStarts{keys.cur, n, jbits, segs.p, cnt.dev(), nullptr}, n + 1, st);
     const uint32_t nseg = cnt.wait(st);
-    const bool ok = narrow ? segsort_tasks_lds<uint32_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st)
-                           : segsort_tasks_lds<uint64_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st);
-    if (!ok) return false;  // hub rows: caller takes the global sort
-    device_for_each(GatherVals<uint64_t>{vals.cur, perm.p, vals.alt}, n, st);
+    DevBuf<uint32_t> perm_alt;
+    bool in_alt = false;
+    const bool ok = narrow ? segsort_tasks_lds<uint32_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st, keys.alt, &perm_alt, &in_alt)
+                           : segsort_tasks_lds<uint64_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st, keys.alt, &perm_alt, &in_alt);
+    if (!ok) return false;  // not handled: the caller takes the global sort
+    if (in_alt) keys.flip();
+    device_for_each(GatherVals<uint64_t>{vals.cur, in_alt ? perm_alt.p : perm.p, vals.alt}, n, st);
     vals.flip();
+    BMSP_HIP(hipStreamSynchronize(st));  // perm_alt goes back to the pool
     return true;
 }
 

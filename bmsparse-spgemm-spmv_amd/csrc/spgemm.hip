@@ -1015,12 +1015,19 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     // segment length -- the reference decides on the task count alone (:963) -- and falls back when a hub row shows up.
     const uint64_t a_block_rows = (uint64_t)A->num_block_rows();
     const uint64_t avg_seg = n_tasks / (a_block_rows ? a_block_rows : 1);
-    const bool try_segmented = mode == BMSP_SORT_SEGMENTED || (mode == BMSP_SORT_AUTO && avg_seg >= 4 && avg_seg <= 2048);
+    // a block-row of C collects at most (most blocks in a block-row of A) x (most blocks in a block-row of B) tasks: when that fits a
+    // wave's register sort, T_5 runs without a single read-back (per-matrix maxima, cached: ensure_row_stats)
+    const uint64_t seg_bound = (uint64_t)std::max<int64_t>(A->max_row_blocks, 0) * (uint64_t)std::max<int64_t>(B->max_row_blocks, 0);
+    // Segments beyond a wave's 4096 words are sorted in pieces and merged (segsort.hip).  Measured: that beats the global radix sort when
+    // every segment needs at most a couple of merge passes (dense-tile ceiling, 4225 tasks per block-row: 2.9 vs 3.8 ms) and loses to it on
+    // power-law rows (R-MAT 2^16, hub segments of 10^5 tasks: 4.5 vs 2.8 ms) -- so AUTO takes it when the operands' row maxima bound every
+    // segment by 4 pieces; BMSP_SEG_AVG_MAX moves the average-length bound for experiments
+    const char *sme = getenv("BMSP_SEG_AVG_MAX");
+    const uint64_t seg_avg_max = sme ? (uint64_t)atoll(sme) : 2048;
+    const bool try_segmented = mode == BMSP_SORT_SEGMENTED ||
+                               (mode == BMSP_SORT_AUTO && avg_seg >= 4 && (avg_seg <= seg_avg_max || (seg_bound > 0 && seg_bound <= 16384)));
     S->sort_path = 0;
     if (n_tasks) {
-        // a block-row of C collects at most (most blocks in a block-row of A) x (most blocks in a block-row of B) tasks: when that fits a
-        // wave's register sort, T_5 runs without a single read-back (per-matrix maxima, cached: ensure_row_stats)
-        const uint64_t seg_bound = (uint64_t)std::max<int64_t>(A->max_row_blocks, 0) * (uint64_t)std::max<int64_t>(B->max_row_blocks, 0);
         if (try_segmented && segsort_tasks_by_column(kk, vv, n_tasks, jbits, st, seg_bound, a_block_rows)) {
             S->sort_path = 1;
             tm.mark(8);

@@ -578,8 +578,8 @@ struct VsLds {
 constexpr int kPre = BMSP_VS_PRE;
 template <typename A>
 struct VsPre {
-    uint64_t k[kVsTpl];
-    uint32_t oe[kVsTpl];
+    uint32_t ti[kVsTpl];  // the tile's slot word {block column, block-row inside the item's window}, from the tile cache
+    uint32_t oe[kVsTpl];  // end of the tile's values relative to the item's first value (multi-batch items only)
     uint32_t e[kPre];
     A a[kPre];
 };
@@ -591,7 +591,7 @@ __host__ __device__ __forceinline__ bool vs_single(const SweepItem &it)
     return it.num_items == 0 && it.blk_end - it.blk_begin <= kVsTiles && vs_item_values(it) <= kVsVals;
 }
 template <typename T>
-__device__ __forceinline__ void vs_request(const SweepItem &it, int lane, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ offsets,
+__device__ __forceinline__ void vs_request(const SweepItem &it, int lane, const uint32_t *__restrict__ tcache, const uint16_t *__restrict__ eoff,
                                            rsrc_t rv, rsrc_t rp, uint32_t pos_base, VsPre<typename Acc<T>::type> &pre)
 {
     const uint32_t bend = min(it.blk_begin + kVsTiles, it.blk_end);
@@ -599,10 +599,10 @@ __device__ __forceinline__ void vs_request(const SweepItem &it, int lane, const 
 #pragma unroll
     for (int t = 0; t < kVsTpl; t++) {
         const uint32_t b = it.blk_begin + 64u * (uint32_t)t + (uint32_t)lane;
-        pre.k[t] = (uint64_t)it.row_begin << 32;
+        pre.ti[t] = 0;
         pre.oe[t] = 0;
-        if (b < bend) pre.k[t] = keys[b];
-        if (!single && b < bend) pre.oe[t] = (uint32_t)offsets[b + 1];
+        if (b < bend) pre.ti[t] = tcache[b];
+        if (!single && b < bend) pre.oe[t] = (uint32_t)eoff[b];
     }
     const uint32_t n_item = vs_item_values(it);
 #pragma unroll
@@ -625,7 +625,8 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
                                                           const T *__restrict__ x, typename Acc<T>::type *__restrict__ y,
                                                           typename Acc<T>::type *__restrict__ carry, uint32_t *__restrict__ counters,
                                                           uint32_t num_rows, uint32_t num_cols, uint32_t values_bytes,
-                                                          uint16_t *__restrict__ pos, uint32_t pos_base, uint32_t pos_count, uint32_t row_lo)
+                                                          uint16_t *__restrict__ pos, uint32_t pos_base, uint32_t pos_count, uint32_t row_lo,
+                                                          uint32_t *__restrict__ tcache, uint16_t *__restrict__ eoff)
 {
     using A = typename Acc<T>::type;
     using L = VsLds<A, MODE, RED>;
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
     const uint32_t item_id = blockIdx.x;
     const SweepItem it = items[item_id];
     VsPre<A> pre;
-    if (MODE == kCached) vs_request<T>(it, lane, keys, offsets, rv, rp, pos_base, pre);
+    if (MODE == kCached) vs_request<T>(it, lane, tcache, eoff, rv, rp, pos_base, pre);
     {
         tile[lane] = A(0);
         tile[64 + lane] = A(0);
@@ -655,18 +656,20 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
             const bool first = MODE == kCached && base == it.blk_begin;
             const uint32_t bend = min(base + kVsTiles, it.blk_end);
             uint64_t bm[kVsTpl], kk[kVsTpl];
+            uint32_t ti[kVsTpl];              // kCached: the tile's slot word straight from the tile cache
             uint32_t ob[kVsTpl], eb[kVsTpl];  // start / end of the tile's values, relative to the batch's first value
             uint32_t v_first = first ? it.val_begin : 0u;
-            if (MODE == kCached && !first) v_first = (uint32_t)offsets[base];
+            uint32_t v_rel = 0;               // kCached, later batches: the batch's first value relative to the item's
+            if (MODE == kCached && !first) { v_rel = (uint32_t)eoff[base - 1]; v_first = it.val_begin + v_rel; }
 #pragma unroll
             for (int t = 0; t < kVsTpl; t++) {
                 const uint32_t b = base + 64u * (uint32_t)t + (uint32_t)lane;
-                bm[t] = 0; kk[t] = (uint64_t)it.row_begin << 32; ob[t] = 0; eb[t] = kOob;
+                bm[t] = 0; kk[t] = (uint64_t)it.row_begin << 32; ob[t] = 0; eb[t] = kOob; ti[t] = 0;
                 if (first) {
-                    kk[t] = pre.k[t];
-                    if (b < bend) eb[t] = single ? 0u : pre.oe[t] - v_first;
+                    ti[t] = pre.ti[t];
+                    if (b < bend) eb[t] = single ? 0u : pre.oe[t];
                 } else if (MODE == kCached) {
-                    if (b < bend) { kk[t] = keys[b]; eb[t] = (uint32_t)offsets[b + 1] - v_first; }
+                    if (b < bend) { ti[t] = tcache[b]; eb[t] = (uint32_t)eoff[b] - v_rel; }
                 } else {
                     if (b < bend) { bm[t] = bmps[b]; kk[t] = keys[b]; ob[t] = (uint32_t)offsets[b]; }
                 }
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
             }
             // tile slots: column and row-in-window of every tile of the batch
 #pragma unroll
-            for (int t = 0; t < kVsTpl; t++) tinfo[64 * t + lane] = key_col(kk[t]) | ((key_row(kk[t]) - it.row_begin) << 28);
+            for (int t = 0; t < kVsTpl; t++) tinfo[64 * t + lane] = MODE == kCached ? ti[t] : (key_col(kk[t]) | ((key_row(kk[t]) - it.row_begin) << 28));
             if (RED == kSorted) {
                 cnt[lane] = 0;
                 cnt[64 + lane] = 0;
@@ -724,6 +727,15 @@ __global__ __launch_bounds__(64, sizeof(typename Acc<T>::type) == 4 ? 8 : 1) voi
             }
             __builtin_amdgcn_wave_barrier();
             if (MODE == kBuild) {
+                // the tile cache: slot word and end of the tile's values relative to the item's first value (every tile of the batch)
+#pragma unroll
+                for (int t = 0; t < kVsTpl; t++) {
+                    const uint32_t b = base + 64u * (uint32_t)t + (uint32_t)lane;
+                    if (ok[t]) {
+                        tcache[b] = key_col(kk[t]) | ((key_row(kk[t]) - it.row_begin) << 28);
+                        eoff[b] = (uint16_t)(v_first + eb[t] - it.val_begin);
+                    }
+                }
                 for (uint32_t idx = (uint32_t)lane; idx < nvals; idx += 64u) pos[v_first - pos_base + idx] = ent[idx];
                 __builtin_amdgcn_wave_barrier();
                 base += nb;
@@ -881,12 +893,18 @@ void build_pos_cache(bmsp_matrix_s *A, hipStream_t st)
     const uint64_t base = A->view_values_end ? read_back(A->offsets, st) : 0;  // a row-panel view keeps the parent's absolute offsets
     const uint64_t count = (uint64_t)A->values_extent() - base;
     if (count == 0 || count * 2 > cap || count >= (1ull << 31)) return;
-    uint16_t *pos = (uint16_t *)pool_alloc(count * 2 + 64);
+    // one allocation: entries (2 B per stored value) | tile slot words (4 B per tile) | tile value ends relative to the item (2 B per tile)
+    const size_t nb = (size_t)A->block_num;
+    const size_t off_ti = (count * 2 + 63) & ~size_t(63), off_eo = off_ti + ((nb * 4 + 63) & ~size_t(63));
+    char *blk = (char *)pool_alloc(off_eo + nb * 2 + 64);
+    uint16_t *pos = (uint16_t *)blk;
+    A->spmv_tinfo = (uint32_t *)(blk + off_ti);
+    A->spmv_eoff = (uint16_t *)(blk + off_eo);
     const char *mem = (const char *)A->spmv_chunks;
     const uint32_t n_items = (uint32_t)A->spmv_num_chunks;
     hipLaunchKernelGGL((spmv_vstream_kernel<float, kBuild, kAtomic>), dim3(n_items), dim3(64), 0, st, (const SweepItem *)(mem + 64), n_items, A->keys,
                        A->bmps, A->offsets, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr,
-                       (uint32_t)A->num_rows, (uint32_t)A->num_cols, 0u, pos, (uint32_t)base, (uint32_t)count, 0u);
+                       (uint32_t)A->num_rows, (uint32_t)A->num_cols, 0u, pos, (uint32_t)base, (uint32_t)count, 0u, A->spmv_tinfo, A->spmv_eoff);
     BMSP_CHECK_LAUNCH();
     A->spmv_pos = pos;
     A->spmv_pos_base = (int64_t)base;
@@ -1101,7 +1119,8 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
     hipLaunchKernelGGL((spmv_vstream_kernel<T, MODE, RED>), dim3(n_items), dim3(64), 0, st, (const SweepItem *)(mem + 64), n_items, A->keys, A->bmps, \
                        A->offsets, (const T *)A->values, (const T *)v, (Ac *)u, (Ac *)(mem + A->spmv_plan_off_carry),                             \
                        (uint32_t *)(mem + A->spmv_plan_off_cnt), row_hi, (uint32_t)A->num_cols,                                                    \
-                       (uint32_t)((size_t)A->values_extent() * sizeof(T)), A->spmv_pos, (uint32_t)A->spmv_pos_base, (uint32_t)A->spmv_pos_count, row_lo)
+                       (uint32_t)((size_t)A->values_extent() * sizeof(T)), A->spmv_pos, (uint32_t)A->spmv_pos_base, (uint32_t)A->spmv_pos_count, row_lo,                     \
+                       A->spmv_tinfo, A->spmv_eoff)
             if (cached && red == kAtomic) BMSP_VS_LAUNCH(kCached, kAtomic);
             else if (cached) BMSP_VS_LAUNCH(kCached, kSorted);
             else if (red == kAtomic) BMSP_VS_LAUNCH(kDecode, kAtomic);
@@ -1128,8 +1147,8 @@ void launch(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t s
 
 // Which kernel bmsp_spmv launches for (A, variant) -- the launcher's own decisions, in its order -- and the bytes that kernel's layout
 // must move per launch ("compulsory": every array it reads or writes, once; counted from the plan, not estimated):
-//   value-stream, position cache: items (32 B) + keys (8 B per tile) + for items that are NOT a single batch the next-offset word of
-//     every tile (8 B: the 4 bytes read sit in an 8-byte stride) + entries (2 B) and values per stored value + x + y + carry slots;
+//   value-stream, position + tile cache: items (32 B) + slot word (4 B per tile) + for items that are NOT a single batch the 2-byte value
+//     end of every tile + entries (2 B) and values per stored value + x + y + carry slots;
 //   value-stream, in-kernel decode: items + keys, bitmaps, offsets (24 B per tile) + values + x + y;
 //   row-group / block-row kernels: block-row pointer + 24 B per tile + values + x + y;   sweep: items + 24 B per tile + values + x + y.
 // format_bytes is SURVEY 8(d)'s figure for the bmSparse layout whatever the kernel reads: 24 B per tile + values + row pointer + x + y.
@@ -1171,7 +1190,7 @@ void spmv_launch_info(bmsp_matrix_s *A, int variant, hipStream_t st, char *kerne
                     if (it.num_items) long_items++;
                 }
                 bytes = 32 * n_items + xy + 64 * long_items + es * nv;
-                bytes += cached ? 8 * nb + 8 * multi_tiles + 2 * nv : 24 * nb;
+                bytes += cached ? 4 * nb + 2 * multi_tiles + 2 * nv : 24 * nb;
             } else {
                 name = A->spmv_full_tiles * 4 >= nb ? "spmv_sweep_kernel<FULL>" : "spmv_sweep_kernel";
                 bytes = 32 * n_items + 24 * nb + es * nv + xy;

@@ -199,7 +199,7 @@ typedef struct {
 #define BMSP_MAC_STAGED 1  /* tc 4: K = 32 MFMA, operands staged through LDS per task (sparse task lists) */
 #define BMSP_MAC_DIRECT 2  /* tc 4: K = 32 MFMA, operand lines loaded per task straight into the MFMA lanes */
 #define BMSP_MAC_STRIP 3   /* tc 4: K = 32 MFMA, two block-rows of C per wave, A tiles register-resident, B tiles loaded once per strip */
-#define BMSP_MAC_F32MFMA 4 /* tc 5, fp32: V15's fmaf chain on v_mfma_f32_16x16x4_f32 */
+#define BMSP_MAC_F32MFMA 4 /* tc 5, fp32, opt-in (BMSP_MAC_F32MFMA=1): V15's fmaf chain on v_mfma_f32_16x16x4_f32, operands from lane-ordered tile copies */
 
 /* sort modes = the reference's `segmented` argument (src/bmSparse_SPGEMM.cu:963-1016):
  * 0 = global sort below BMSP_SORT_BORDER surviving tasks, segmented sort above; 1 = always segmented;
@@ -228,8 +228,9 @@ int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, in
 int bmsp_selftest_mfma_layout(int *mismatches);
 /* Hardware self test of the ACCUMULATION ORDER of v_mfma_f32_16x16x4_f32: D = C + A * B on random fp32 operands against the host chain
  * fmaf(a_k, b_k, sum) for k ascending -- the order of multiplyV15<float, float> (src/bmSparse_SPGEMM.cu:269-273 as nvcc contracts it).
- * *mismatches = number of result elements that differ in any bit.  With 0 the fp32 product (tc_version 5) runs its block-MAC on the
- * matrix cores (BMSP_MAC_F32MFMA) with values bit-identical to the vector-ALU kernel; otherwise it stays on the vector ALU. */
+ * *mismatches = number of result elements that differ in any bit (0 on gfx950).  With 0 the fp32 product (tc_version 5) CAN run its
+ * block-MAC on the matrix cores with values bit-identical to the vector-ALU kernel (BMSP_MAC_F32MFMA=1 selects that kernel; it is not the
+ * default: measured on MI355X it is bound by the 256-byte operand tiles it reads and no faster than the vector-ALU kernels). */
 int bmsp_selftest_mfma_f32_chain(int *mismatches);
 
 /* bb_segsort<K,T>(keys, vals, n, segs, length)  -- include/bb_segsort-master/bb_segsort.h:35-192,

@@ -547,6 +547,33 @@ def test_mfma32_block_mac_paths(oracle, bmsp, monkeypatch, case, b_dense, quota)
         np.testing.assert_allclose(vn, vo, rtol=2e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("case", ["two_pieces", "three_pieces", "rmat_hubs"])
+def test_spgemm_long_segments_merge(oracle, bmsp, monkeypatch, case, wide):
+    """T_5, segmented path, block-rows whose task segment exceeds what a wave sorts in registers (4096 words, 2048 with 64-bit sort
+    words): the segment is cut into pieces, the pieces are sorted like ordinary segments and merged by merge-path passes (one pass +
+    the copy back for two pieces, two passes for three or four, a hub-row mix on R-MAT).  The fp32 V15 values are compared BIT FOR BIT:
+    they depend on the order of the tasks inside every C tile, i.e. on the sort being stable across piece boundaries."""
+    from pybmsp import gen
+    if wide:
+        monkeypatch.setenv("BMSP_SEGSORT_WIDE", "1")
+    if case == "rmat_hubs":
+        n, _, r, c, v = gen.rmat(12, 8)
+        A = Bc = (n, n, r, c, v)
+    else:
+        # 2 block-rows x 300 block-columns of A, all full; B's block-rows hold 20 / 40 tiles: 6000 / 12000 tasks per block-row of C
+        nb_cols = 20 if case == "two_pieces" else 40
+        nk = 8 * 300
+        r = np.repeat(np.arange(16), nk); c = np.tile(np.arange(nk), 16)
+        A = (16, nk, r, c, np.sin(r * 7.0 + c))
+        rb = np.repeat(np.arange(nk), 8 * nb_cols); cb = np.tile(np.arange(8 * nb_cols), nk)
+        Bc = (nk, 8 * nb_cols, rb, cb, np.cos(rb * 3.0 + cb))
+    st = check_spgemm(oracle, bmsp, A, Bc, 0, 1, 5)
+    assert st["sort_path"] == 1, st          # the segmented path took it (before round 3 a long segment fell back to the radix sort)
+    st2 = check_spgemm(oracle, bmsp, A, Bc, 1, 1, 4)
+    assert st2["sort_path"] == 1
+
+
 def test_mfma_f32_accumulation_order(bmsp):
     """v_mfma_f32_16x16x4_f32 accumulates its four k as the ascending fmaf chain (checked on the hardware against a host fmaf chain on
     random operands of mixed magnitude): the property the fp32 matrix-core block-MAC (BMSP_MAC_F32MFMA) rests on."""
@@ -559,9 +586,10 @@ def test_mfma_f32_accumulation_order(bmsp):
 @pytest.mark.parametrize("quota", ["64", ""])
 @pytest.mark.parametrize("case", ["rmat", "banded_full", "hub_c_blocks", "rect_ragged", "fem", "cancel"])
 def test_f32_mfma_block_mac(oracle, bmsp, monkeypatch, case, quota):
-    """tc_version 5 on fp32 operands through block_mac_f32_mfma_kernel (forced on every task-count profile, default and smallest wave
-    quota): V15's numerics -- the values must equal the oracle's k-ascending fmaf chain BIT FOR BIT on random fp32 values, and the
-    vector-ALU kernel's on the same operands; `cancel` has sums that end in +0 / -0 and C tiles of unequal task counts in one pair."""
+    """tc_version 5 on fp32 operands through block_mac_f32_mfma_kernel (opt-in, operands from lane-ordered tile copies; every task-count
+    profile, default and smallest wave quota): V15's numerics -- the values must equal the oracle's k-ascending fmaf chain BIT FOR BIT on
+    random fp32 values, and the vector-ALU kernel's on the same operands; `cancel` has sums that end in +0 / -0 and C tiles of unequal
+    task counts in one pair."""
     from pybmsp import gen
     monkeypatch.setenv("BMSP_MAC_F32MFMA", "1")
     if quota:
