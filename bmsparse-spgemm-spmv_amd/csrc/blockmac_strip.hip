@@ -121,9 +121,23 @@ __device__ __forceinline__ uint32_t merge_sorted(StripLds &S, uint32_t n0, uint3
 
 // what a k-group's scan needs from memory, requested one k-group ahead: keys and bitmaps of the next 32 tiles of B's block-row k
 struct ScanPre {
-    uint64_t key[2], bmp[2];
+    uint32_t col[2];   // block column of the tile (the low word of its key)
+    uint64_t bmp[2];   // its bitmap: only requested where the bitmap filter can drop a pair (some column of the strip's A tiles is empty)
     uint32_t cur, end;
+    bool filter;
 };
+
+// OR over the wave, in every lane's copy of the result register of lane 63 (DPP row shifts + row broadcasts: no LDS traffic)
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 // PAIRS = column pairs of a window (2 PAIRS C-tile columns of the strip, 4 PAIRS accumulator registers), NB = B lines (column pairs) a wave
 // requests together, OCC = waves per SIMD the register allocation is held to
@@ -210,13 +224,16 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     auto request = [&](const Item &it) {
         ScanPre pre;
         const uint32_t u = 4 * it.gi + (uint32_t)ks;
-        pre.cur = 0; pre.end = 0;
-        if (it.on && u < nK) { pre.cur = S.kcur[u]; pre.end = S.kend[u]; }
+        pre.cur = 0; pre.end = 0; pre.filter = false;
+        if (it.on && u < nK) { pre.cur = S.kcur[u]; pre.end = S.kend[u]; pre.filter = S.kcm[u] != 0xffu; }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t t = pre.cur + (uint32_t)(16 * h + q16);
-            pre.key[h] = 0; pre.bmp[h] = 0;
-            if (t < pre.end) { pre.key[h] = g.b_keys[t]; pre.bmp[h] = g.b_bmps[t]; }
+            pre.col[h] = 0; pre.bmp[h] = ~0ull;
+            if (t < pre.end) {
+                pre.col[h] = ((const uint32_t *)g.b_keys)[2 * (size_t)t];  // little-endian: the key's low word is the block column
+                if (pre.filter) pre.bmp[h] = g.b_bmps[t];
+            }
         }
         return pre;
     };
@@ -232,12 +249,13 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
         const uint32_t u = 4 * it.gi + (uint32_t)ks;
         const bool u_on = u < nK;
         const uint32_t cm = u_on ? S.kcm[u] : 0u;
+        uint32_t mine = 0;
         for (;;) {
             uint32_t hits = 0;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const uint32_t t = pre.cur + (uint32_t)(16 * h + q16);
-                const uint32_t j = key_col(pre.key[h]);
+                const uint32_t j = pre.col[h];
                 const bool inwin = t < pre.end && j <= jhi;
                 if (inwin) {
                     uint32_t sl;
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
                     // present in C's strip and not dropped by the bitmap filter (the tile's non-empty rows against the columns in use)
                     if (found && (cm & tile_or_bytes(pre.bmp[h])) != 0u) {
                         S.sched[tb][ks][sl & 1u][sl >> 1] = t + 1u;
-                        atomicOr(&S.pmask[tb], 1u << (sl >> 1));
+                        mine |= 1u << (sl >> 1);
                     }
                 }
                 hits += (uint32_t)__popcll((__ballot(inwin) >> (16 * ks)) & 0xffffull);
@@ -258,11 +276,17 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const uint32_t t = pre.cur + (uint32_t)(16 * h + q16);
-                pre.key[h] = 0; pre.bmp[h] = 0;
-                if (t < pre.end) { pre.key[h] = g.b_keys[t]; pre.bmp[h] = g.b_bmps[t]; }
+                pre.col[h] = 0; pre.bmp[h] = ~0ull;
+                if (t < pre.end) {
+                    pre.col[h] = ((const uint32_t *)g.b_keys)[2 * (size_t)t];
+                    if (pre.filter) pre.bmp[h] = g.b_bmps[t];
+                }
             }
         }
         if (u_on && q16 == 0) S.kcur[u] = pre.cur;
+        // the column pairs of the window that got a tile: one OR over the wave (an LDS atomic per lane would serialise on one word)
+        const uint32_t all = wave_or_u32(mine);
+        if (lane == 0) S.pmask[tb] = all;
     };
 
     Item cur{0u, 0u, true};

@@ -2,6 +2,16 @@
 """Condenses a tools/profile.sh output directory (gpurun_out/<name>) into profiles/<tag>_*.{csv,md} (tracked)."""
 import csv, glob, collections, os, shutil, sys
 
+
+def profiled_commit(src):
+    """the commit the profiled tree was at: <src>/commit.txt (written by the person launching the gpurun call, `git rev-parse --short HEAD`
+    on a clean tree), else None -- bench.py only quotes counter figures that carry this stamp and whose kernel sources have not changed since"""
+    try:
+        return open(os.path.join(src, "commit.txt")).read().strip() or None
+    except OSError:
+        return None
+
+
 src, tag, kern = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "spmv_sweep")
 cmd = sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --skip-cpu --skip-spgemm --steps 100 --warmup 10"
 os.makedirs("profiles", exist_ok=True)
@@ -49,7 +59,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             a = agg[row["Counter_Name"]]; a[0] += 1; a[1] += float(row["Counter_Value"])
     for c, (n, sm) in agg.items(): tot[c] = sm / n
 if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
-    tr = {"kernel": kern, "fetch_size_kib": tot["FETCH_SIZE"], "write_size_kib": tot["WRITE_SIZE"],
+    tr = {"kernel": kern, "profiled_at_commit": profiled_commit(src), "fetch_size_kib": tot["FETCH_SIZE"], "write_size_kib": tot["WRITE_SIZE"],
           "traffic_bytes_per_launch": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024),
           "method": "2*FETCH_SIZE + WRITE_SIZE (KiB), separate --pmc passes; factor 2 calibrated by experiments/fetch_calib.hip"}
     json.dump(tr, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
