@@ -34,10 +34,13 @@ namespace bmsp {
 namespace {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2k_t __attribute__((ext_vector_type(2)));
 
 constexpr int kKCap = 192;  // merged A tiles of a strip (two block-rows)
 constexpr int kJCap = 512;  // merged C tiles of a strip
 constexpr uint32_t kNone = 0xffffffffu;
+constexpr int kStageTile = 72;             // floats per staged C tile: 64 + 8, so the four tiles of a pair start in different LDS banks
+constexpr uint32_t kNoTile = 0xffffff00u;  // schedule word of an absent tile: a byte offset no line offset brings back into a buffer
 
 struct StripArgs {
     const uint64_t *a_keys, *a_bmps;
@@ -54,17 +57,22 @@ struct StripArgs {
     uint32_t block_rows;  // of A and C
 };
 
-struct StripLds {
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte store at 4-byte alignment
+
+struct alignas(16) StripLds {
     uint32_t jj[kJCap];        // merged column list of the strip's C tiles
     uint16_t jc[kJCap][2];     // C tile of row 0 / row 1 relative to the row's first tile; 0xffff = none
     uint32_t kk[kKCap];        // merged k list
-    uint32_t ka[kKCap][2];     // A tile of row 0 / row 1 (absolute index; kNone)
+    uint32_t ka[kKCap][2];     // A tile of row 0 / row 1: its byte offset in A's dense copy (kNoTile = none)
     uint32_t kcur[kKCap];      // B's block-row k: next tile not yet consumed
     uint32_t kend[kKCap];
     uint32_t kcm[kKCap];       // OR of the column masks of the strip's A tiles in column k
-    uint32_t l0[kJCap / 2], l1[kJCap / 2];  // merge temporaries (the two sorted lists)
+    union {
+        struct { uint32_t l0[kJCap / 2], l1[kJCap / 2]; };  // merge temporaries (the two sorted lists)
+        float stage[4 * kStageTile];                        // after the merges: the four C tiles of a column pair on their way out
+    };
     uint16_t nd[kJCap / 2 + 2];             // non-duplicates among the first q entries of l1
-    uint32_t sched[2][4][2][16];  // two tables (item n & 1) x [k slot][column of the pair][pair]: B tile index + 1; 0 = none
+    uint32_t sched[2][4][2][16];  // two tables (item n & 1) x [k slot][column of the pair][pair]: byte offset of the B tile in its dense copy; kNoTile = none
     uint32_t pmask[2];            // column pairs of the item's window with any tile of its k-group
 };
 
@@ -159,6 +167,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     if (i0 >= g.block_rows) return;
     const bool two = i0 + 1 < g.block_rows;
     const rsrc_t rda = make_rsrc(g.a_dense, g.a_dense_bytes), rdb = make_rsrc(g.b_dense, g.b_dense_bytes);
+    const rsrc_t rbk = make_rsrc(g.b_keys, g.b_dense_bytes >> 4), rbb = make_rsrc(g.b_bmps, g.b_dense_bytes >> 4);  // 8 bytes per block
 
     // ---- the strip's rows of A and C ----
     const uint32_t a0b = g.a_rowptr[i0], a0e = g.a_rowptr[i0 + 1], a1e = two ? g.a_rowptr[i0 + 2] : a0e;
@@ -169,12 +178,12 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     // ---- merged k list ----
     for (uint32_t p = (uint32_t)lane; p < n0; p += 64) S.l0[p] = key_col(g.a_keys[a0b + p]);
     for (uint32_t q = (uint32_t)lane; q < n1; q += 64) S.l1[q] = key_col(g.a_keys[a0e + q]);
-    for (uint32_t u = (uint32_t)lane; u < (uint32_t)kKCap; u += 64) { S.ka[u][0] = kNone; S.ka[u][1] = kNone; S.kcm[u] = 0u; }
+    for (uint32_t u = (uint32_t)lane; u < (uint32_t)kKCap; u += 64) { S.ka[u][0] = kNoTile; S.ka[u][1] = kNoTile; S.kcm[u] = 0u; }
     __builtin_amdgcn_wave_barrier();
     const uint32_t nK = merge_sorted(S, n0, n1, lane, [&](uint32_t pos, uint32_t k, uint32_t p, uint32_t q) {
         const uint32_t a = p != kNone ? a0b + p : a0e + q;
         S.kk[pos] = k;
-        S.ka[pos][p != kNone ? 0 : 1] = a;
+        S.ka[pos][p != kNone ? 0 : 1] = a << 7;
         atomicOr(&S.kcm[pos], tile_or_bytes(g.a_bmps[a]));  // column k' of the tile holds a value <=> bit (7 - k')
     });
     __builtin_amdgcn_wave_barrier();
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     for (uint32_t p = (uint32_t)lane; p < m0; p += 64) S.l0[p] = key_col(g.c_keys[c0b + p]);
     for (uint32_t q = (uint32_t)lane; q < m1; q += 64) S.l1[q] = key_col(g.c_keys[c0e + q]);
     for (uint32_t s = (uint32_t)lane; s < (uint32_t)kJCap; s += 64) { S.jc[s][0] = 0xffffu; S.jc[s][1] = 0xffffu; }
-    for (uint32_t s = (uint32_t)lane; s < 256u; s += 64) ((uint32_t *)S.sched)[s] = 0u;
+    for (uint32_t s = (uint32_t)lane; s < 256u; s += 64) ((uint32_t *)S.sched)[s] = kNoTile;
     if (lane < 2) S.pmask[lane] = 0u;
     __builtin_amdgcn_wave_barrier();
     const uint32_t nJ = merge_sorted(S, m0, m1, lane, [&](uint32_t pos, uint32_t j, uint32_t p, uint32_t q) {
@@ -203,6 +212,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     const int ks = lane >> 4;                          // K slot of the MFMA = entry of the k-group
     const int half_sel = (lane >> 3) & 1;              // A operand: block-row of the strip; B operand: column of the pair
     const int line = lane & 7;                         // tile row (A) / tile column (B)
+    const uint32_t line16 = (uint32_t)(line * 16);
     const int q16 = lane & 15;                         // scan: tile q16 / q16 + 16 behind the cursor of k slot ks
     const int d_row = lane >> 5;                       // result: block-row of the strip this lane's D values belong to
     const uint32_t d_r0 = 4u * (uint32_t)((lane >> 4) & 1);  // first of its four tile rows
@@ -230,9 +240,11 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
         for (int h = 0; h < 2; h++) {
             const uint32_t t = pre.cur + (uint32_t)(16 * h + q16);
             pre.col[h] = 0; pre.bmp[h] = ~0ull;
-            if (t < pre.end) {
-                pre.col[h] = ((const uint32_t *)g.b_keys)[2 * (size_t)t];  // little-endian: the key's low word is the block column
-                if (pre.filter) pre.bmp[h] = g.b_bmps[t];
+            // (little-endian: the key's low word is the block column; a tile past the block-row's end is requested out of range)
+            pre.col[h] = __builtin_amdgcn_raw_buffer_load_b32(rbk, t < pre.end ? t << 3 : kOob, 0, 0);
+            if (pre.filter) {
+                const u32x2k_t bm = __builtin_amdgcn_raw_buffer_load_b64(rbb, t < pre.end ? t << 3 : kOob, 0, 0);
+                pre.bmp[h] = ((uint64_t)bm[1] << 32) | bm[0];
             }
         }
         return pre;
@@ -263,8 +275,8 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
                     if (dense_win) { sl = j - jlo; found = j >= jlo; }
                     else { sl = lds_lower_bound(S.jj + s0, ns, j); found = sl < ns && S.jj[s0 + sl] == j; }
                     // present in C's strip and not dropped by the bitmap filter (the tile's non-empty rows against the columns in use)
-                    if (found && (cm & tile_or_bytes(pre.bmp[h])) != 0u) {
-                        S.sched[tb][ks][sl & 1u][sl >> 1] = t + 1u;
+                    if (found && (!pre.filter || (cm & tile_or_bytes(pre.bmp[h])) != 0u)) {
+                        S.sched[tb][ks][sl & 1u][sl >> 1] = t << 7;
                         mine |= 1u << (sl >> 1);
                     }
                 }
@@ -277,9 +289,10 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
             for (int h = 0; h < 2; h++) {
                 const uint32_t t = pre.cur + (uint32_t)(16 * h + q16);
                 pre.col[h] = 0; pre.bmp[h] = ~0ull;
-                if (t < pre.end) {
-                    pre.col[h] = ((const uint32_t *)g.b_keys)[2 * (size_t)t];
-                    if (pre.filter) pre.bmp[h] = g.b_bmps[t];
+                pre.col[h] = __builtin_amdgcn_raw_buffer_load_b32(rbk, t < pre.end ? t << 3 : kOob, 0, 0);
+                if (pre.filter) {
+                    const u32x2k_t bm = __builtin_amdgcn_raw_buffer_load_b64(rbb, t < pre.end ? t << 3 : kOob, 0, 0);
+                    pre.bmp[h] = ((uint64_t)bm[1] << 32) | bm[0];
                 }
             }
         }
@@ -304,8 +317,8 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
         // ---- requests of the item: the A operand (line `line` of A(row half_sel, k slot ks)) and the B lines of its first NB active
         //      column pairs -- straight-line code (an absent pair's request goes out of range and moves nothing), so that the
         //      compiler's wait counts stay exact.  The item's schedule was scattered one iteration ago. ----
-        const uint32_t a = u < nK ? S.ka[u][half_sel] : kNone;
-        const half8_t fa = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rda, a != kNone ? (a << 7) + (uint32_t)(line * 16) : kOob, 0, 0));
+        const uint32_t a = S.ka[min(u, (uint32_t)kKCap - 1u)][half_sel];  // entries past nK hold kNoTile
+        const half8_t fa = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rda, a + line16, 0, 0));
         const uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.pmask[tb]);
         const uint32_t *my = S.sched[tb][ks][half_sel];
         const Item nn = next_item(nxt);
@@ -327,8 +340,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
 #pragma unroll
                 for (int q = 0; q < NB; q++) {
                     if ((mb >> q) & 1u) {
-                        const uint32_t b1 = my[NB * hb + q];
-                        fb[q] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rdb, b1 ? ((b1 - 1u) << 7) + (uint32_t)(line * 16) : kOob, 0, 0));
+                        fb[q] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rdb, my[NB * hb + q] + line16, 0, 0));
                     }
                 }
                 if (!scanned) { scan_next(); scanned = true; }
@@ -341,27 +353,59 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
         if (!scanned) scan_next();
         __builtin_amdgcn_wave_barrier();
         // clear the item's schedule (512 bytes: one 8-byte store per lane); the item after next will scatter into it
-        ((uint64_t *)S.sched[tb])[lane] = 0ull;
+        ((uint64_t *)S.sched[tb])[lane] = ((uint64_t)kNoTile << 32) | kNoTile;
         if (lane == 0) S.pmask[tb] = 0u;
         __builtin_amdgcn_wave_barrier();
         if (cur.gi + 1 == nG) {
             // ---- the window is complete: lane holds D[4 * (lane >> 4) + i][lane & 15] = rows d_r0 + i of C(row d_row, column 2p + half_sel) ----
             const uint32_t s0 = SLOTS * cur.wi, ns = min(SLOTS, nJ - s0);
             const uint32_t crow0 = d_row ? c0e : c0b;
+            // A lane's four D values are one column of half a tile: through LDS they become 16 consecutive bytes of a tile row, so a
+            // full C tile leaves as one 256-byte run (16 lanes x 16 bytes); tiles with holes take the per-value path
+            const int o_row = lane >> 5, o_col = (lane >> 4) & 1, o_q = lane & 15;  // outgoing layout: tile (o_row, column o_col of the pair), floats 4 o_q .. 4 o_q + 3
+            float *const st_in = S.stage + (d_row * 2 + half_sel) * kStageTile + (int)d_r0 * 8 + line;
+            const float *const st_out = S.stage + (o_row * 2 + o_col) * kStageTile + 4 * o_q;
+            const uint32_t orow0 = o_row ? c0e : c0b;
+            constexpr int PG = 4;  // pairs whose C words are requested together
 #pragma unroll
-            for (int p = 0; p < PAIRS; p++) {
-                const uint32_t sl = 2u * (uint32_t)p + (uint32_t)half_sel;
-                const uint32_t crel = sl < ns ? (uint32_t)S.jc[s0 + sl][d_row] : 0xffffu;
-                if (crel != 0xffffu) {
-                    const uint32_t c = crow0 + crel;
-                    const uint64_t cb = g.c_bmps[c], co = g.c_offs[c];
+            for (int p0 = 0; p0 < PAIRS; p0 += PG) {
+                if (2u * (uint32_t)p0 < ns) {
+                    uint64_t ocb[PG], oco[PG];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const uint32_t pos = (d_r0 + (uint32_t)i) * 8u + (uint32_t)line;
-                        if ((cb >> (63u - pos)) & 1ull) g.c_vals[co + (uint64_t)__popcll(cb >> 1 >> (63u - pos))] = acc[p][i];
+                    for (int q = 0; q < PG; q++) {
+                        const uint32_t sl = 2u * (uint32_t)(p0 + q) + (uint32_t)o_col;
+                        const uint32_t crel = sl < ns ? (uint32_t)S.jc[s0 + sl][o_row] : 0xffffu;
+                        ocb[q] = ~0ull; oco[q] = ~0ull;  // no tile: nothing to store, and no reason to leave the fast path
+                        if (crel != 0xffffu) { ocb[q] = g.c_bmps[orow0 + crel]; oco[q] = g.c_offs[orow0 + crel]; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < PG; q++) {
+                        const int p = p0 + q;
+                        if (2u * (uint32_t)p >= ns) continue;
+                        if (__all(ocb[q] == ~0ull)) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) st_in[8 * i] = acc[p][i];
+                            __builtin_amdgcn_wave_barrier();
+                            const float4_t v = *(const float4_t *)st_out;
+                            if (oco[q] != ~0ull) *(float4_u *)(g.c_vals + oco[q] + 4u * (uint32_t)o_q) = v;
+                            __builtin_amdgcn_wave_barrier();
+                        } else {
+                            const uint32_t sl = 2u * (uint32_t)p + (uint32_t)half_sel;
+                            const uint32_t crel = sl < ns ? (uint32_t)S.jc[s0 + sl][d_row] : 0xffffu;
+                            if (crel != 0xffffu) {
+                                const uint32_t c = crow0 + crel;
+                                const uint64_t cb = g.c_bmps[c], co = g.c_offs[c];
+#pragma unroll
+                                for (int i = 0; i < 4; i++) {
+                                    const uint32_t pos = (d_r0 + (uint32_t)i) * 8u + (uint32_t)line;
+                                    if ((cb >> (63u - pos)) & 1ull) g.c_vals[co + (uint64_t)__popcll(cb >> 1 >> (63u - pos))] = acc[p][i];
+                                }
+                            }
+                        }
                     }
                 }
-                acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < PG; q++) acc[p0 + q] = float4_t{0.f, 0.f, 0.f, 0.f};
             }
         }
         cur = nxt; nxt = nn;
@@ -433,7 +477,9 @@ void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipS
     const uint32_t strips = (g.block_rows + 1) / 2;
     // Measured on MI355X (T_7, us; dense-tile ceiling / FEM-like forced): 16 pairs per window, 8 lines requested together, 3 waves per SIMD
     // 840 / 637; 16 lines together at 2 waves per SIMD 975 / 736, at 3 waves (28 spilled registers) 1580 / 878; 8-pair windows 881 / 662;
-    // one workgroup per strip (shared tables, windows dealt to the four waves, cursors re-seeded per window) 1058 / 692.
+    // one workgroup per strip (shared tables, windows dealt to the four waves, cursors re-seeded per window) 1058 / 692.  Timing-only builds
+    // of the 803 us kernel on the ceiling case: the next item's scan run twice +208 us, the B lines requested out of range -99 us; C tiles
+    // leaving as 256-byte runs through LDS instead of per-value stores: 803 -> 776 us.
     const dim3 grid((strips + 3) / 4);
     if (getenv("BMSP_STRIP_WIDE")) hipLaunchKernelGGL((block_mac_strip_kernel<16, 16, 2>), grid, dim3(kThreads), 0, st, g);  // experiment switch
     else hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3>), grid, dim3(kThreads), 0, st, g);

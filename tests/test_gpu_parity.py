@@ -1100,6 +1100,29 @@ def test_row_panel_views_fp16_mfma_and_spmv(oracle, bmsp):
     assert not yp[: lo * 8].any() and not yp[hi * 8:].any()
 
 
+def test_spmv_launch_info_counts_the_launched_layout(bmsp):
+    """bmsp_spmv_launch_info: the kernel the launcher picks and the bytes that kernel's layout must move, counted from the plan.  Sparse
+    tiles -> value-stream kernel over the caches: 32 B per item + 4 B per tile (+ 2 B per tile of multi-batch items) + 6 B per fp32 value
+    + x + y, well below the 24-B-per-tile format figure; dense tiles -> row-group kernel: the format figure itself."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(14, 2)
+    A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
+    info, li = A.info(), bmsp.spmv_launch_info(A)
+    assert li["kernel"].startswith("spmv_vstream_kernel<kCached")
+    nbr = (n + 7) // 8
+    assert li["format_bytes"] == 24 * info["block_num"] + 4 * info["nnz"] + 4 * (nbr + 1) + 8 * n
+    lo = 4 * info["block_num"] + 6 * info["nnz"] + 8 * n                   # slot words + entries + values + x + y
+    assert lo < li["compulsory_bytes"] <= lo + 2 * info["block_num"] + 40 * info["block_num"] // 64 + 4096, li   # + value ends, items, carry slots
+    assert li["compulsory_bytes"] < li["format_bytes"]
+    y = bmsp.spmv(A, bmsp.DeviceArray.from_host(np.ones(n, np.float32))).to_host()     # the plan it counted is the plan that runs
+    assert abs(float(y.sum()) - float(np.asarray(v, np.float32).astype(np.float64).sum())) <= 1e-3 * abs(float(v.sum()))
+    n2, _, r2, c2, v2 = gen.banded(4096, 16)
+    D = bmsp.BmSpMatrix.from_coo(n2, n2, r2, c2, v2)
+    ld = bmsp.spmv_launch_info(D)
+    assert ld["kernel"] == "spmv_rowgroup_kernel" and ld["compulsory_bytes"] == ld["format_bytes"]
+    assert bmsp.spmv_launch_info(D, variant=1)["kernel"].startswith("spmv_blockrow_kernel")
+
+
 def test_sharded_operators_through_c_abi_one_rank(oracle, bmsp):
     """bmsp_comm_init / bmsp_spgemm_sharded / bmsp_spmv_sharded over a real RCCL communicator of one rank (all a one-GPU box
     allows: RCCL refuses two ranks on one device): the unique-id rendezvous, the size all-gather, the broadcast of the panel into
