@@ -35,6 +35,7 @@ namespace {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x2k_t __attribute__((ext_vector_type(2)));
+typedef float f32x2k_t __attribute__((ext_vector_type(2)));
 
 constexpr int kKCap = 192;  // merged A tiles of a strip (two block-rows)
 constexpr int kJCap = 512;  // merged C tiles of a strip
@@ -45,12 +46,12 @@ constexpr uint32_t kNoTile = 0xffffff00u;  // schedule word of an absent tile: a
 struct StripArgs {
     const uint64_t *a_keys, *a_bmps;
     const uint32_t *a_rowptr;
-    const _Float16 *a_dense;
+    const void *a_dense;      // fp16: tiles in position order, 128 B each; fp32: tiles in MFMA lane order (ensure_lane_tiles), 256 B each
     uint32_t a_dense_bytes;
     const uint64_t *b_keys, *b_bmps;
     const uint32_t *b_rowptr;
-    const _Float16 *b_dense;
-    uint32_t b_dense_bytes, b_block_rows;
+    const void *b_dense;
+    uint32_t b_dense_bytes, b_block_rows, b_blocks;
     const uint64_t *c_keys, *c_bmps, *c_offs;
     const uint32_t *c_rowptr;
     float *c_vals;
@@ -73,7 +74,7 @@ struct alignas(16) StripLds {
     };
     uint16_t nd[kJCap / 2 + 2];             // non-duplicates among the first q entries of l1
     uint32_t sched[2][4][2][16];  // two tables (item n & 1) x [k slot][column of the pair][pair]: byte offset of the B tile in its dense copy; kNoTile = none
-    uint32_t pmask[2];            // column pairs of the item's window with any tile of its k-group
+    alignas(16) uint32_t pmask[2][4];  // per k slot: column pairs of the item's window with a tile of B's block-row k
 };
 
 __device__ __forceinline__ uint32_t lds_lower_bound(const uint32_t *a, uint32_t n, uint32_t v)
@@ -135,21 +136,21 @@ struct ScanPre {
     bool filter;
 };
 
-// OR over the wave, in every lane's copy of the result register of lane 63 (DPP row shifts + row broadcasts: no LDS traffic)
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+// OR over each row of 16 lanes, valid in the row's lane 15 (DPP row shifts: no LDS traffic)
+__device__ __forceinline__ uint32_t row_or_u32(uint32_t v)
 {
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return v;
 }
 
 // PAIRS = column pairs of a window (2 PAIRS C-tile columns of the strip, 4 PAIRS accumulator registers), NB = B lines (column pairs) a wave
 // requests together, OCC = waves per SIMD the register allocation is held to
-template <int PAIRS, int NB, int OCC>
+// F32: fp32 operands on v_mfma_f32_16x16x4_f32 -- the k slots of an item are walked one after the other (two instructions per tile: kk 0-3,
+// kk 4-7), which is V15's summation order exactly (ascending fmaf chain, established on the hardware by mfma_f32_selftest)
+template <int PAIRS, int NB, int OCC, bool F32 = false>
 __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArgs g)
 {
     __shared__ StripLds lds_all[4];
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     if (i0 >= g.block_rows) return;
     const bool two = i0 + 1 < g.block_rows;
     const rsrc_t rda = make_rsrc(g.a_dense, g.a_dense_bytes), rdb = make_rsrc(g.b_dense, g.b_dense_bytes);
-    const rsrc_t rbk = make_rsrc(g.b_keys, g.b_dense_bytes >> 4), rbb = make_rsrc(g.b_bmps, g.b_dense_bytes >> 4);  // 8 bytes per block
+    const rsrc_t rbk = make_rsrc(g.b_keys, g.b_blocks << 3), rbb = make_rsrc(g.b_bmps, g.b_blocks << 3);
+    constexpr uint32_t TS = F32 ? 8u : 7u;  // log2 of a tile's bytes in the operand copies
 
     // ---- the strip's rows of A and C ----
     const uint32_t a0b = g.a_rowptr[i0], a0e = g.a_rowptr[i0 + 1], a1e = two ? g.a_rowptr[i0 + 2] : a0e;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     const uint32_t nK = merge_sorted(S, n0, n1, lane, [&](uint32_t pos, uint32_t k, uint32_t p, uint32_t q) {
         const uint32_t a = p != kNone ? a0b + p : a0e + q;
         S.kk[pos] = k;
-        S.ka[pos][p != kNone ? 0 : 1] = a << 7;
+        S.ka[pos][p != kNone ? 0 : 1] = a << TS;
         atomicOr(&S.kcm[pos], tile_or_bytes(g.a_bmps[a]));  // column k' of the tile holds a value <=> bit (7 - k')
     });
     __builtin_amdgcn_wave_barrier();
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     for (uint32_t q = (uint32_t)lane; q < m1; q += 64) S.l1[q] = key_col(g.c_keys[c0e + q]);
     for (uint32_t s = (uint32_t)lane; s < (uint32_t)kJCap; s += 64) { S.jc[s][0] = 0xffffu; S.jc[s][1] = 0xffffu; }
     for (uint32_t s = (uint32_t)lane; s < 256u; s += 64) ((uint32_t *)S.sched)[s] = kNoTile;
-    if (lane < 2) S.pmask[lane] = 0u;
+    if (lane < 8) ((uint32_t *)S.pmask)[lane] = 0u;
     __builtin_amdgcn_wave_barrier();
     const uint32_t nJ = merge_sorted(S, m0, m1, lane, [&](uint32_t pos, uint32_t j, uint32_t p, uint32_t q) {
         S.jj[pos] = j;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
                     else { sl = lds_lower_bound(S.jj + s0, ns, j); found = sl < ns && S.jj[s0 + sl] == j; }
                     // present in C's strip and not dropped by the bitmap filter (the tile's non-empty rows against the columns in use)
                     if (found && (!pre.filter || (cm & tile_or_bytes(pre.bmp[h])) != 0u)) {
-                        S.sched[tb][ks][sl & 1u][sl >> 1] = t << 7;
+                        S.sched[tb][ks][sl & 1u][sl >> 1] = t << TS;
                         mine |= 1u << (sl >> 1);
                     }
                 }
@@ -297,9 +299,10 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
             }
         }
         if (u_on && q16 == 0) S.kcur[u] = pre.cur;
-        // the column pairs of the window that got a tile: one OR over the wave (an LDS atomic per lane would serialise on one word)
-        const uint32_t all = wave_or_u32(mine);
-        if (lane == 0) S.pmask[tb] = all;
+        // the column pairs of the window that got a tile of k slot ks: an OR over the slot's 16 lanes (DPP row shifts; an LDS atomic per lane
+        // would serialise on one word)
+        const uint32_t all = row_or_u32(mine);
+        if (q16 == 15) S.pmask[tb][ks] = all;
     };
 
     Item cur{0u, 0u, true};
@@ -313,14 +316,6 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     for (int p = 0; p < PAIRS; p++) acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
     uint32_t tb = 0;
     while (cur.on) {
-        const uint32_t u = 4 * cur.gi + (uint32_t)ks;
-        // ---- requests of the item: the A operand (line `line` of A(row half_sel, k slot ks)) and the B lines of its first NB active
-        //      column pairs -- straight-line code (an absent pair's request goes out of range and moves nothing), so that the
-        //      compiler's wait counts stay exact.  The item's schedule was scattered one iteration ago. ----
-        const uint32_t a = S.ka[min(u, (uint32_t)kKCap - 1u)][half_sel];  // entries past nK hold kNoTile
-        const half8_t fa = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rda, a + line16, 0, 0));
-        const uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.pmask[tb]);
-        const uint32_t *my = S.sched[tb][ks][half_sel];
         const Item nn = next_item(nxt);
         // while the item's B lines travel: the scan of the next item into the other table, and the key request of the one after
         auto scan_next = [&]() {
@@ -328,25 +323,71 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
             __builtin_amdgcn_wave_barrier();
             pre = request(nn);
         };
+        typedef uint32_t u32x4k_t __attribute__((ext_vector_type(4)));
+        const u32x4k_t pm4 = *(const u32x4k_t *)S.pmask[tb];
+        bool scanned = false;
         // The column pairs are walked with STATIC indices (accumulator registers cannot be indexed; a switch over the pair number makes
         // the compiler copy the accumulator file around every case) in batches of NB: requests of the batch's active pairs (wave-uniform
-        // branches), then -- once per item -- the next item's scan, then the batch's MFMAs.
-        bool scanned = false;
+        // branches; an absent tile's request goes out of range and moves nothing, so the compiler's wait counts stay exact), then -- once
+        // per item -- the next item's scan, then the batch's MFMAs.  The item's schedule was scattered one iteration ago.
+        if constexpr (!F32) {
+            // the A operand: line `line` of A(row half_sel, k slot ks); the four k slots share every instruction
+            const uint32_t u = 4 * cur.gi + (uint32_t)ks;
+            const uint32_t a = S.ka[min(u, (uint32_t)kKCap - 1u)][half_sel];  // entries past nK hold kNoTile
+            const half8_t fa = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rda, a + line16, 0, 0));
+            const uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pm4[0] | pm4[1] | pm4[2] | pm4[3]));
+            const uint32_t *my = S.sched[tb][ks][half_sel];
 #pragma unroll
-        for (int hb = 0; hb < PAIRS / NB; hb++) {
-            const uint32_t mb = (pm >> (NB * hb)) & ((1u << NB) - 1u);
-            if (mb) {
-                half8_t fb[NB];
+            for (int hb = 0; hb < PAIRS / NB; hb++) {
+                const uint32_t mb = (pm >> (NB * hb)) & ((1u << NB) - 1u);
+                if (mb) {
+                    half8_t fb[NB];
 #pragma unroll
-                for (int q = 0; q < NB; q++) {
-                    if ((mb >> q) & 1u) {
-                        fb[q] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rdb, my[NB * hb + q] + line16, 0, 0));
+                    for (int q = 0; q < NB; q++) {
+                        if ((mb >> q) & 1u) {
+                            fb[q] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rdb, my[NB * hb + q] + line16, 0, 0));
+                        }
+                    }
+                    if (!scanned) { scan_next(); scanned = true; }
+#pragma unroll
+                    for (int q = 0; q < NB; q++) {
+                        if ((mb >> q) & 1u) acc[NB * hb + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[q], acc[NB * hb + q], 0, 0, 0);
                     }
                 }
-                if (!scanned) { scan_next(); scanned = true; }
+            }
+        } else {
+            // lane (kq = ks, line) holds elements (line, kk = kq) and (line, kk = kq + 4) of its tile: 8 consecutive bytes of the lane-ordered copy
+            const uint32_t lane8 = (uint32_t)(line * 32 + ks * 8);
+            f32x2k_t fa[4];  // (float vectors: __builtin_bit_cast(float, v[1]) of an integer vector's element reads element 0 with this compiler)
 #pragma unroll
-                for (int q = 0; q < NB; q++) {
-                    if ((mb >> q) & 1u) acc[NB * hb + q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[q], acc[NB * hb + q], 0, 0, 0);
+            for (int k4 = 0; k4 < 4; k4++) {
+                const uint32_t a = S.ka[min(4 * cur.gi + (uint32_t)k4, (uint32_t)kKCap - 1u)][half_sel];
+                fa[k4] = __builtin_bit_cast(f32x2k_t, __builtin_amdgcn_raw_buffer_load_b64(rda, a + lane8, 0, 0));
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 4; k4++) {
+                const uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pm4[k4]);
+                const uint32_t *my = S.sched[tb][k4][half_sel];
+#pragma unroll
+                for (int hb = 0; hb < PAIRS / NB; hb++) {
+                    const uint32_t mb = (pm >> (NB * hb)) & ((1u << NB) - 1u);
+                    if (mb) {
+                        f32x2k_t fb[NB];
+#pragma unroll
+                        for (int q = 0; q < NB; q++) {
+                            if ((mb >> q) & 1u) fb[q] = __builtin_bit_cast(f32x2k_t, __builtin_amdgcn_raw_buffer_load_b64(rdb, my[NB * hb + q] + lane8, 0, 0));
+                        }
+                        if (!scanned) { scan_next(); scanned = true; }
+#pragma unroll
+                        for (int q = 0; q < NB; q++) {
+                            if ((mb >> q) & 1u) {
+                                float4_t c = acc[NB * hb + q];
+                                c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k4][0], fb[q][0], c, 0, 0, 0);  // kk 0 .. 3
+                                c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k4][1], fb[q][1], c, 0, 0, 0);  // kk 4 .. 7
+                                acc[NB * hb + q] = c;
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -354,7 +395,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
         __builtin_amdgcn_wave_barrier();
         // clear the item's schedule (512 bytes: one 8-byte store per lane); the item after next will scatter into it
         ((uint64_t *)S.sched[tb])[lane] = ((uint64_t)kNoTile << 32) | kNoTile;
-        if (lane == 0) S.pmask[tb] = 0u;
+        if (lane < 4) S.pmask[tb][lane] = 0u;
         __builtin_amdgcn_wave_barrier();
         if (cur.gi + 1 == nG) {
             // ---- the window is complete: lane holds D[4 * (lane >> 4) + i][lane & 15] = rows d_r0 + i of C(row d_row, column 2p + half_sel) ----
@@ -413,7 +454,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
     }
 }
 
-// fp16 values that are not finite (exponent all ones): a skipped candidate pair must contribute an exact zero
+// values that are not finite (exponent all ones): a skipped candidate pair must contribute an exact zero
 struct NonFiniteF16 {
     const uint16_t *v;
     uint32_t *flag;
@@ -422,29 +463,64 @@ struct NonFiniteF16 {
         if ((v[i] & 0x7c00u) == 0x7c00u) *flag = 1u;
     }
 };
+struct NonFiniteF32 {
+    const uint32_t *v;
+    uint32_t *flag;
+    __device__ void operator()(uint64_t i) const
+    {
+        if ((v[i] & 0x7f800000u) == 0x7f800000u) *flag = 1u;
+    }
+};
 
 }  // namespace
 
 void ensure_finite_flag(bmsp_matrix_s *m, hipStream_t st)
 {
     if (m->values_finite >= 0) return;
-    if (m->dtype != BMSP_F16 || m->nnz == 0) { m->values_finite = 1; return; }
+    if (m->dtype == BMSP_F64 || m->nnz == 0) { m->values_finite = 1; return; }
     DevBuf<uint32_t> flag(1);
     BMSP_HIP(hipMemsetAsync(flag.p, 0, 4, st));
     const uint64_t base = m->view_values_end ? read_back(m->offsets, st) : 0;
-    device_for_each(NonFiniteF16{(const uint16_t *)m->values + base, flag.p}, (uint64_t)m->values_extent() - base, st);
+    const uint64_t n = (uint64_t)m->values_extent() - base;
+    if (m->dtype == BMSP_F16) device_for_each(NonFiniteF16{(const uint16_t *)m->values + base, flag.p}, n, st);
+    else device_for_each(NonFiniteF32{(const uint32_t *)m->values + base, flag.p}, n, st);
     m->values_finite = read_back(flag.p, st) ? 0 : 1;
 }
 
-// whether the strip kernel takes this product (decided from cached per-matrix figures; the two read-backs behind them happen once per matrix)
-bool mac_strip_eligible(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, uint64_t candidates, uint64_t n_tasks, hipStream_t st)
+// what the strip kernel needs of the operands alone: fp16 tiles the K = 32 MFMA path addresses, a strip's merged A tiles within the k
+// list, finite values (cached per-matrix figures; the read-backs behind them happen once per matrix)
+bool mac_strip_operands_ok(bmsp_matrix_s *A, bmsp_matrix_s *B, hipStream_t st)
 {
-    const char *force = getenv("BMSP_MAC_STRIP");  // 0 / 1: experiment and test switch (the capacity limits below still hold)
-    if (force && force[0] == '0') return false;
-    if (!mac_mfma32_supported(A, B) || C->block_num >= (1ll << 31) || C->block_num == 0) return false;
+    if (A->dtype == BMSP_F16) {
+        if (!mac_mfma32_supported(A, B)) return false;
+    } else if (A->dtype == BMSP_F32) {
+        // 256-byte tiles behind 32-bit byte offsets; the instruction's summation order is checked on the device once per process
+        if (B->dtype != BMSP_F32 || A->block_num >= (1ll << 24) || B->block_num >= (1ll << 24) || !mac_f32_mfma_usable(st)) return false;
+    } else {
+        return false;
+    }
     if ((uint64_t)A->num_block_rows() >= (1ull << 31)) return false;
     ensure_row_stats(A, st);
     if (2 * A->max_row_blocks > kKCap) return false;
+    ensure_finite_flag(A, st);
+    ensure_finite_flag(B, st);
+    return A->values_finite == 1 && B->values_finite == 1;
+}
+
+// ... and of C: a strip's merged C tiles within the column list (two block-rows of at most mac_strip_row_cap() tiles always fit)
+uint32_t mac_strip_row_cap() { return (uint32_t)kJCap / 2u; }
+bool mac_strip_fits_c(bmsp_matrix_s *C, hipStream_t st)
+{
+    if (C->block_num >= (1ll << 31) || C->block_num == 0) return false;
+    ensure_row_stats(C, st);
+    return 2 * C->max_row_blocks <= kJCap;
+}
+
+// whether the strip kernel takes a product whose task list exists (the task-list kernels are the alternative)
+bool mac_strip_eligible(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, uint64_t candidates, uint64_t n_tasks, hipStream_t st)
+{
+    const char *force = getenv("BMSP_MAC_STRIP");  // 0 / 1: experiment and test switch (the capacity limits still hold)
+    if (force && force[0] == '0') return false;
     if (!force) {
         // The walk visits every candidate pair and pays a fixed price per (window, k-group) item: it wins where items are fat -- C tiles
         // that collect many tasks from candidate pairs that nearly all survive (dense-tile ceiling: 32.8 tasks per C tile, 840 us against
@@ -452,26 +528,24 @@ bool mac_strip_eligible(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, ui
         // direct kernel stays ahead (530 vs 640 us), so the bar sits between the two.
         if (n_tasks < 20 * (uint64_t)C->block_num || 10 * n_tasks < 9 * candidates) return false;
     }
-    ensure_row_stats(C, st);
-    if (2 * C->max_row_blocks > kJCap) return false;
-    ensure_finite_flag(A, st);
-    ensure_finite_flag(B, st);
-    return A->values_finite == 1 && B->values_finite == 1;
+    return mac_strip_fits_c(C, st) && mac_strip_operands_ok(A, B, st);
 }
 
 void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st)
 {
-    ensure_dense_tiles(A, st);
-    ensure_dense_tiles(B, st);
+    const bool f32 = A->dtype == BMSP_F32;
+    if (f32) { ensure_lane_tiles(A, st); ensure_lane_tiles(B, st); }
+    else { ensure_dense_tiles(A, st); ensure_dense_tiles(B, st); }
     ensure_rowptr(A, st);
     ensure_rowptr(B, st);
     ensure_rowptr(C, st);
     StripArgs g{};
+    const uint32_t tile_bytes = f32 ? 256u : 128u;
     g.a_keys = A->keys; g.a_bmps = A->bmps; g.a_rowptr = A->rowptr;
-    g.a_dense = (const _Float16 *)A->dense_tiles; g.a_dense_bytes = (uint32_t)(A->block_num * 128);
+    g.a_dense = f32 ? A->lane_tiles : A->dense_tiles; g.a_dense_bytes = (uint32_t)A->block_num * tile_bytes;
     g.b_keys = B->keys; g.b_bmps = B->bmps; g.b_rowptr = B->rowptr;
-    g.b_dense = (const _Float16 *)B->dense_tiles; g.b_dense_bytes = (uint32_t)(B->block_num * 128);
-    g.b_block_rows = (uint32_t)B->num_block_rows();
+    g.b_dense = f32 ? B->lane_tiles : B->dense_tiles; g.b_dense_bytes = (uint32_t)B->block_num * tile_bytes;
+    g.b_block_rows = (uint32_t)B->num_block_rows(); g.b_blocks = (uint32_t)B->block_num;
     g.c_keys = C->keys; g.c_bmps = C->bmps; g.c_offs = C->offsets; g.c_rowptr = C->rowptr; g.c_vals = (float *)C->values;
     g.block_rows = (uint32_t)A->num_block_rows();
     const uint32_t strips = (g.block_rows + 1) / 2;
@@ -481,7 +555,8 @@ void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipS
     // of the 803 us kernel on the ceiling case: the next item's scan run twice +208 us, the B lines requested out of range -99 us; C tiles
     // leaving as 256-byte runs through LDS instead of per-value stores: 803 -> 776 us.
     const dim3 grid((strips + 3) / 4);
-    if (getenv("BMSP_STRIP_WIDE")) hipLaunchKernelGGL((block_mac_strip_kernel<16, 16, 2>), grid, dim3(kThreads), 0, st, g);  // experiment switch
+    if (f32) hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3, true>), grid, dim3(kThreads), 0, st, g);
+    else if (getenv("BMSP_STRIP_WIDE")) hipLaunchKernelGGL((block_mac_strip_kernel<16, 16, 2>), grid, dim3(kThreads), 0, st, g);  // experiment switch
     else hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3>), grid, dim3(kThreads), 0, st, g);
     BMSP_CHECK_LAUNCH();
 }

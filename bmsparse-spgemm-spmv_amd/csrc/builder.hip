@@ -394,6 +394,7 @@ void invalidate_matrix(bmsp_matrix_s *m, int structure_changed)
     m->values_finite = -1;
     if (!structure_changed) return;
     pool_free(m->rowptr); m->rowptr = nullptr; m->rowptr_rows = 0; m->max_row_blocks = -1;
+    m->rm_reject_keys = nullptr; m->rm_reject_blocks = 0;
     pool_free(m->spmv_chunks); m->spmv_chunks = nullptr; m->spmv_num_chunks = 0; m->spmv_plan_long = 0; m->spmv_full_tiles = 0;
     pool_free(m->spmv_pos); m->spmv_pos = nullptr; m->spmv_tinfo = nullptr; m->spmv_eoff = nullptr; m->spmv_pos_base = 0; m->spmv_pos_count = 0; m->spmv_pos_tried = 0;
     pool_free(m->block_meta); m->block_meta = nullptr;
@@ -411,13 +412,9 @@ void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st)
 }
 
 namespace {
-struct RowMaxBlocks {
+struct RowBlocksIn {
     const uint32_t *rowptr;
-    uint32_t *out;
-    __device__ void operator()(uint64_t r) const
-    {
-        atomicMax(out, rowptr[r + 1] - rowptr[r]);  // once per matrix
-    }
+    __device__ uint64_t operator()(uint64_t r) const { return (uint64_t)(rowptr[r + 1] - rowptr[r]); }
 };
 }  // namespace
 
@@ -428,9 +425,9 @@ void ensure_row_stats(bmsp_matrix_s *m, hipStream_t st)
     ensure_rowptr(m, st);
     const int64_t nbr = m->num_block_rows();
     if (nbr == 0) { m->max_row_blocks = 0; return; }
-    DevBuf<uint32_t> mx(1);
-    BMSP_HIP(hipMemsetAsync(mx.p, 0, 4, st));
-    device_for_each(RowMaxBlocks{m->rowptr, mx.p}, (uint64_t)nbr, st);
+    DevBuf<unsigned long long> mx(1);
+    BMSP_HIP(hipMemsetAsync(mx.p, 0, 8, st));
+    device_max_sum(RowBlocksIn{m->rowptr}, (uint64_t)nbr, mx.p, (unsigned long long *)nullptr, st);
     m->max_row_blocks = (int64_t)read_back(mx.p, st);
 }
 

@@ -435,6 +435,42 @@ void device_for_each(F f, uint64_t n, hipStream_t st)
     BMSP_CHECK_LAUNCH();
 }
 
+// max and sum of in(i) over [0, n): grid-stride partial results, ONE pair of atomics per workgroup (same-address device atomics from
+// every wave serialise at the memory side: ~30 ns each on MI355X, 4 ms for 131 K rows).  *out_max / *out_sum must be zeroed by the caller;
+// either may be null.  In: uint64_t operator()(uint64_t i) const
+template <typename In>
+__global__ __launch_bounds__(kThreads) void max_sum_kernel(In in, uint64_t n, unsigned long long *out_max, unsigned long long *out_sum)
+{
+    __shared__ unsigned long long lmax[4], lsum[4];
+    unsigned long long mx = 0, sm = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) {
+        const unsigned long long v = in(i);
+        mx = v > mx ? v : mx;
+        sm += v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(mx, d, kWave);
+        mx = o > mx ? o : mx;
+    }
+    sm = wave_sum(sm);
+    if (lane_id() == 0) { lmax[wave_id()] = mx; lsum[wave_id()] = sm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { mx = lmax[w] > mx ? lmax[w] : mx; sm += lsum[w]; }
+        if (out_max) atomicMax(out_max, mx);
+        if (out_sum) atomicAdd(out_sum, sm);
+    }
+}
+template <typename In>
+void device_max_sum(In in, uint64_t n, unsigned long long *out_max, unsigned long long *out_sum, hipStream_t st)
+{
+    if (n == 0) return;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + kThreads - 1) / kThreads, 256);
+    hipLaunchKernelGGL((max_sum_kernel<In>), dim3(grid), dim3(kThreads), 0, st, in, n, out_max, out_sum);
+    BMSP_CHECK_LAUNCH();
+}
+
 // A scalar a kernel hands to the host: the slot is pinned host memory the device writes straight into, so fetching it is a
 // stream synchronise and a host load -- no copy kernel, no staging (read_back below costs a blit launch per scalar).
 void *host_slot_acquire();

@@ -951,6 +951,93 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     if (total >= (1ull << 32))  // bmsp_spgemm retries in block-row panels (shard.hip: spgemm_paneled)
         throw TaskRangeExceeded(BMSP_ERR_LIMIT, std::to_string(total) + " candidate block pairs exceed the 32-bit range of one task list");
 
+    std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> C(new bmsp_matrix_s(), free_matrix);
+    C->num_rows = A->num_rows; C->num_cols = B->num_cols;  // :1171-1172
+    C->dtype = A->dtype == BMSP_F64 ? BMSP_F64 : BMSP_F32;  // OUTPUT_TYPE float (:51)
+    C->transposed = 0;
+    // value offsets and nnz from C's bitmaps, C's value array (the tail of T_9)
+    auto finish_structure = [&]() -> uint64_t {
+        const uint32_t c_size = (uint32_t)C->block_num;
+        uint64_t c_nnz = 0;
+        C->offsets = (uint64_t *)pool_alloc(8 * ((size_t)c_size + 1));
+        if (c_size) {
+            HostScalar<uint64_t> c_nnz_h;
+            device_exclusive_scan<uint64_t>(PopcIn{C->bmps, c_size}, PtrOutTotal<uint64_t>{C->offsets, c_size, c_nnz_h.dev()}, (uint64_t)c_size + 1, st);
+            c_nnz = c_nnz_h.wait(st);
+        } else {
+            BMSP_HIP(hipMemsetAsync(C->offsets, 0, 8, st));
+        }
+        C->nnz = (int64_t)c_nnz;
+        C->values = pool_alloc(dtype_size(C->dtype) * (size_t)(c_nnz ? c_nnz : 1));
+        return c_nnz;
+    };
+    auto finish = [&]() {
+        BMSP_HIP(hipStreamSynchronize(st));  // reference: cudaDeviceSynchronize (:1158)
+        S->t_us[0] = tm.collect(S->t_us);
+        S->t_us[5] += S->t_us[8];  // the reference's T_5 includes its "Segmented sort" sub-timer (:1009-1024)
+        if (verbose) {
+            // the reference's VERBOSE lines, in its order (src/bmSparse_SPGEMM.cu:849-1164)
+            print_stage(true, "T_1", S->t_us[1]);
+            print_stage(true, "T_2", S->t_us[2]);
+            printf("Task list size: %llu\n", (unsigned long long)total);
+            print_stage(true, "T_3", S->t_us[3]);
+            printf("Bmp reduction: %lld\n", (long long)S->bmp_reduction);
+            print_stage(true, "T_4", S->t_us[4]);
+            if (S->sort_path == 1) print_stage(true, "Segmented sort", S->t_us[8]);
+            print_stage(true, "T_5", S->t_us[5]);
+            print_stage(true, "T_6", S->t_us[6]);
+            print_stage(true, "T_9", S->t_us[9]);
+            print_stage(true, "T_7", S->t_us[7]);
+        }
+        S->c_blocks = C->block_num;
+        S->c_nnz = C->nnz;
+        *Cout = C.release();
+    };
+
+    // Row-merge path (rowmerge.hip): the symbolic stages in one LDS-resident pass per block-row, the numeric stage by the strip kernel,
+    // no task list.  Taken when the sort mode is left to the library, the operands fit the strip kernel and every block-row of C fits the
+    // pass; a product that turns out not to fit costs the pass (FEM-like: ROWMERGE_US us) and continues below.  BMSP_SPGEMM_ROWMERGE=0/1
+    // switches it off / takes it whenever it fits.
+    {
+        const char *rme = getenv("BMSP_SPGEMM_ROWMERGE");
+        const bool rm_force = rme && rme[0] == '1', rm_off = rme && rme[0] == '0';
+        // numeric stages that work from C's structure alone: the K = 32 MFMA strip kernel (tc_version 4, fp16) and its fp32 form (V15's
+        // summation order on v_mfma_f32_16x16x4_f32: any tc_version, as fp32 operands always take V15's numerics)
+        const bool rm_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || (A->dtype == BMSP_F32 && !getenv("BMSP_MAC_VALU_DENSE") && !getenv("BMSP_MAC_F32MFMA"));
+        bool try_rm = !rm_off && total && rm_numeric && (mode == BMSP_SORT_AUTO || rm_force) &&
+                      !(A->rm_reject_keys == (const void *)B->keys && A->rm_reject_blocks == B->block_num);
+        if (try_rm) {
+            const char *sf = getenv("BMSP_MAC_STRIP");
+            try_rm = !(sf && sf[0] == '0') && mac_strip_operands_ok(A, B, st);
+        }
+        if (try_rm) {
+            uint64_t surv = 0;
+            if (rowmerge_symbolic(A, B, C.get(), first_pos.p, total, mac_strip_row_cap(), &surv, st)) {
+                if (C->block_num == 0 || mac_strip_fits_c(C.get(), st)) {
+                    tm.mark(3);
+                    S->surviving_tasks = (int64_t)surv;
+                    S->bmp_reduction = (int64_t)(total - surv);
+                    S->sort_path = BMSP_SORT_PATH_ROWMERGE;
+                    finish_structure();
+                    tm.mark(9);
+                    if (C->block_num) {
+                        launch_mac_strip(A, B, C.get(), st);
+                        S->mac_variant = BMSP_MAC_STRIP;
+                        S->mac_kernel = mfma ? tc_version : 5;
+                    }
+                    tm.mark(7);
+                    finish();
+                    return;
+                }
+                // C exists but a strip of it exceeds the kernel's column list: drop it and build the task list
+                pool_free(C->keys); pool_free(C->bmps); pool_free(C->rowptr);
+                C->keys = nullptr; C->bmps = nullptr; C->rowptr = nullptr; C->rowptr_rows = 0; C->max_row_blocks = -1; C->block_num = 0;
+            }
+            A->rm_reject_keys = B->keys; A->rm_reject_blocks = B->block_num;  // (a pass that ran and did not fit: not again for this pair)
+            tm.mark(-1);
+        }
+    }
+
     // T_3 + T_4: expansion fused with the bitmap filter
     const int jbits = std::max(1, ceil_log2_u64((uint64_t)B->num_block_cols()));
     const int ibits = std::max(1, ceil_log2_u64((uint64_t)A->num_block_rows()));
@@ -1050,32 +1137,20 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
                                         n_tasks + 1, st);
         c_size = csize_h.wait(st);
     }
-    std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> C(new bmsp_matrix_s(), free_matrix);
-    C->num_rows = A->num_rows; C->num_cols = B->num_cols;  // :1171-1172
-    C->dtype = A->dtype == BMSP_F64 ? BMSP_F64 : BMSP_F32;  // OUTPUT_TYPE float (:51)
-    C->transposed = 0;
     C->block_num = c_size;
     C->keys = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
     C->bmps = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
-    C->offsets = (uint64_t *)pool_alloc(8 * ((size_t)c_size + 1));
     if (c_size) BMSP_HIP(hipMemcpyAsync(C->keys, c_keys_scratch.p, 8 * (size_t)c_size, hipMemcpyDeviceToDevice, st));
     tm.mark(6);
 
     // T_9: C bitmaps, value offsets, nnz
-    uint64_t c_nnz = 0;
     if (c_size) {
         device_for_each(ZeroU64{C->bmps}, (uint64_t)c_size, st);  // one launch (hipMemsetAsync splits into two fill kernels)
         hipLaunchKernelGGL(c_bitmaps_kernel, dim3((uint32_t)((n_tasks + 255) / 256)), dim3(kThreads), 0, st, kk.cur, vv.cur, (uint32_t)n_tasks, c_of_wave.p,
                            A->bmps, B->bmps, (unsigned long long *)C->bmps);
         BMSP_CHECK_LAUNCH();
-        HostScalar<uint64_t> c_nnz_h;
-        device_exclusive_scan<uint64_t>(PopcIn{C->bmps, c_size}, PtrOutTotal<uint64_t>{C->offsets, c_size, c_nnz_h.dev()}, (uint64_t)c_size + 1, st);
-        c_nnz = c_nnz_h.wait(st);
-    } else {
-        BMSP_HIP(hipMemsetAsync(C->offsets, 0, 8, st));
     }
-    C->nnz = (int64_t)c_nnz;
-    C->values = pool_alloc(dtype_size(C->dtype) * (size_t)(c_nnz ? c_nnz : 1));
+    finish_structure();
     tm.mark(9);
 
     // T_7: block multiply-accumulate
@@ -1121,27 +1196,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         }
     }
     tm.mark(7);
-    BMSP_HIP(hipStreamSynchronize(st));  // reference: cudaDeviceSynchronize (:1158)
-    S->t_us[0] = tm.collect(S->t_us);
-    S->t_us[5] += S->t_us[8];  // the reference's T_5 includes its "Segmented sort" sub-timer (:1009-1024)
-    if (verbose) {
-        // the reference's VERBOSE lines, in its order (src/bmSparse_SPGEMM.cu:849-1164)
-        print_stage(true, "T_1", S->t_us[1]);
-        print_stage(true, "T_2", S->t_us[2]);
-        printf("Task list size: %llu\n", (unsigned long long)total);
-        print_stage(true, "T_3", S->t_us[3]);
-        printf("Bmp reduction: %lld\n", (long long)S->bmp_reduction);
-        print_stage(true, "T_4", S->t_us[4]);
-        if (S->sort_path == 1) print_stage(true, "Segmented sort", S->t_us[8]);
-        print_stage(true, "T_5", S->t_us[5]);
-        print_stage(true, "T_6", S->t_us[6]);
-        print_stage(true, "T_9", S->t_us[9]);
-        print_stage(true, "T_7", S->t_us[7]);
-    }
-
-    S->c_blocks = c_size;
-    S->c_nnz = (int64_t)c_nnz;
-    *Cout = C.release();
+    finish();
 }
 
 }  // namespace bmsp

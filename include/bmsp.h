@@ -189,12 +189,14 @@ typedef struct {
     int64_t c_nnz;           /* "C nnz" (symbolic) */
     double t_us[10];         /* device time per stage, microseconds: [1]=T_1 [2]=T_2 [3]=T_3 [4]=T_4 [5]=T_5
                                 [6]=T_6 [7]=T_7 [9]=T_9 ; [0]=whole call ("Toda F"); [8]=segmented sort only */
-    int sort_path;           /* 0 = global radix sort (reference: thrust::sort), 1 = segmented sort */
+    int sort_path;           /* 0 = global radix sort (reference: thrust::sort), 1 = segmented sort, 2 = none: C's structure formed
+                              * block-row by block-row in LDS (BMSP_SORT_PATH_ROWMERGE; T_3 then holds the whole symbolic pass) */
     int mac_kernel;          /* which block-MAC kernel ran (see tc_version) */
     int mac_variant;         /* which implementation of it: BMSP_MAC_* below */
     int reserved;
 } bmsp_spgemm_stats;
 /* implementations behind one tc_version (the launcher picks by the product's shape; all give the tc_version's numerics) */
+#define BMSP_SORT_PATH_ROWMERGE 2
 #define BMSP_MAC_DEFAULT 0 /* the only kernel of that tc_version (V15 vector-ALU kernels, K = 16 MFMA kernels) */
 #define BMSP_MAC_STAGED 1  /* tc 4: K = 32 MFMA, operands staged through LDS per task (sparse task lists) */
 #define BMSP_MAC_DIRECT 2  /* tc 4: K = 32 MFMA, operand lines loaded per task straight into the MFMA lanes */

@@ -712,6 +712,54 @@ def test_strip_block_mac(oracle, bmsp, monkeypatch, case):
         assert st2["mac_variant"] != 3
 
 
+@pytest.mark.parametrize("case", ["banded64", "banded_wide", "fem", "fem_int", "rect_ragged", "filtered_run", "empty_strips", "all_filtered",
+                                  "rmat_hub", "cage"])
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_spgemm_rowmerge_path(oracle, bmsp, monkeypatch, case, dtype):
+    """BMSP_SPGEMM_ROWMERGE=1: C's structure formed block-row by block-row in LDS (rowmerge.hip: hash of the surviving pairs' columns, OR of
+    the tile-product bitmaps, rank by column) instead of expand - sort - compress.  Stage counters, keys, bitmaps and offsets are the
+    oracle's bit for bit; the values are the strip kernel's, hence bit-identical with the pipeline + strip kernel on the same operands.  A
+    block-row of C beyond the pass's capacity (rmat_hub) must fall back to the pipeline.  dtype 0: fp32 operands, the strip kernel on
+    v_mfma_f32_16x16x4_f32 -- V15's summation order, so the values are the oracle's (and the vector-ALU kernel's) bit for bit."""
+    from pybmsp import gen
+    exact = False
+    if case == "all_filtered":  # A only touches column 0 of every tile, B only row 7: every candidate pair dies in the bitmap filter
+        n = 2048
+        ra = np.arange(n); ca = (ra // 8) * 8
+        rb = (np.arange(n) // 8) * 8 + 7; cb = np.arange(n)
+        A, Bc, exact = (n, n, ra, ca, np.ones(n)), (n, n, rb, cb, np.ones(n)), True
+    elif case == "rmat_hub":    # hub block-rows of C with thousands of tiles
+        n, _, r, c, v = gen.rmat(13, 16)
+        A = Bc = (n, n, r, c, np.round(v * 8) / 8)
+    elif case == "cage":        # irregular columns: ~70 C tiles per block-row (at most 177), few tasks per C tile
+        n, _, r, c, v = gen.cage_like(40000, per_row=3.0)
+        A = Bc = (n, n, r, c, np.round(v * 64) / 64)
+    else:
+        A, Bc, exact = _strip_case(gen, oracle, case)
+        if Bc is None:
+            Bc = A
+    tc = 4 if dtype == 1 else 5
+    monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "1")
+    st = check_spgemm(oracle, bmsp, A, Bc, dtype, 0, tc, exact_expected=exact)
+    if case == "rmat_hub":
+        assert st["sort_path"] != 2, st
+        return
+    assert st["sort_path"] == 2 and (st["c_blocks"] == 0 or (st["mac_variant"] == 3 and st["mac_kernel"] == tc)), st
+    a = bmsp.BmSpMatrix.from_coo(*A, dtype=dtype)
+    b = bmsp.BmSpMatrix.from_coo(*Bc, transposed=True, dtype=dtype)
+    new, _ = bmsp.spgemm(a, b, tc_version=tc)
+    monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "0")
+    monkeypatch.setenv("BMSP_MAC_STRIP", "1")
+    old, sto = bmsp.spgemm(a, b, tc_version=tc)
+    assert sto["sort_path"] in (0, 1) and (dtype == 1 or sto["mac_variant"] == 0)
+    for x, y in zip(old.host_arrays(), new.host_arrays()):
+        np.testing.assert_array_equal(x, y)
+    # an explicit sort mode is honoured: the pipeline runs
+    monkeypatch.delenv("BMSP_SPGEMM_ROWMERGE")
+    _, st2 = bmsp.spgemm(a, b, mode=2, tc_version=tc)
+    assert st2["sort_path"] == 0
+
+
 @pytest.mark.parametrize("case", ["rmat", "banded", "filtered", "rect"])
 def test_spgemm_single_pass_expansion(oracle, bmsp, monkeypatch, case):
     """BMSP_EXPAND_LOOKBACK: T_3 + T_4 as one decoupled look-back pass (survivors written at the running prefix of the earlier tiles);
