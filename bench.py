@@ -397,6 +397,10 @@ def stage_bytes(st, sort_bits):
     """compulsory bytes of the symbolic stages for THIS pipeline's layout (8-byte packed C key + 8-byte task per surviving pair; DESIGN.md
     section 4 states them next to SURVEY 8(d)'s figures for the reference's 16-byte tasks): per candidate pair / surviving task / C block."""
     cand, surv, cb = st["task_list_size"], st["surviving_tasks"], st["c_blocks"]
+    if st["sort_path"] == 2:
+        # row-merge path (rowmerge.hip): ONE pass reads key + bitmap of B's tile for every candidate pair and writes C's key + bitmap once
+        # (scratch, then its final place); T_3 holds the whole pass, T_9 the popcount scan
+        return {"T_3": 16 * cand + 2 * 16 * cb + 12 * cb, "T_9": 16 * cb}
     passes = -(-sort_bits // 9)
     return {
         "T_3": 16 * cand,                              # count pass: the two bitmaps of every candidate pair
@@ -457,7 +461,7 @@ def bench_spgemm(B, gen, np, args):
         t_mac = best["t_us"][7] * 1e-6
         f_mac = 1024.0 * best["surviving_tasks"]
         peak = MFMA_F16_PEAK_TFLOPS if dtype == B.F16 else FP32_PEAK_TFLOPS
-        kernel_files = ["bmsparse-spgemm-spmv_amd/csrc/blockmac_strip.hip", "bmsparse-spgemm-spmv_amd/csrc/blockmac32.hip", "bmsparse-spgemm-spmv_amd/csrc/blockmac_f32.hip",
+        kernel_files = ["bmsparse-spgemm-spmv_amd/csrc/blockmac_strip.hip", "bmsparse-spgemm-spmv_amd/csrc/rowmerge.hip", "bmsparse-spgemm-spmv_amd/csrc/blockmac32.hip", "bmsparse-spgemm-spmv_amd/csrc/blockmac_f32.hip",
                         "bmsparse-spgemm-spmv_amd/csrc/spgemm.hip"]
         traffic, traffic_src = profile_value("r*_%s_traffic.json" % ptag, "traffic_bytes_per_launch", kernel_files)
         roof = {"bound": "mfma" if dtype == B.F16 else "fp32 matrix / vector rate", "kernel": MAC_VARIANT.get(best.get("mac_variant", 0), "?"),
@@ -485,7 +489,7 @@ def bench_spgemm(B, gen, np, args):
                     "stage_us": {k: round(best["t_us"][i], 1) for k, i in stage_idx},
                     "stage_GBs": {k: round(sb[k] / max(best["t_us"][i], 1e-3) / 1e3, 1) for k, i in stage_idx if k in sb},
                     "stage_frac_of_hbm_peak": {k: round(sb[k] / max(best["t_us"][i], 1e-3) / 1e3 / HBM_PEAK_GBS, 4) for k, i in stage_idx if k in sb},
-                    "sort_path": "segmented" if best["sort_path"] else "global radix",
+                    "sort_path": {0: "global radix", 1: "segmented", 2: "none (row-merge: C's structure formed per block-row in LDS)"}[best["sort_path"]],
                     "roofline": roof})
         del A, At
         B.check(B.lib().bmsp_trim_pool())

@@ -394,7 +394,7 @@ void invalidate_matrix(bmsp_matrix_s *m, int structure_changed)
     m->values_finite = -1;
     if (!structure_changed) return;
     pool_free(m->rowptr); m->rowptr = nullptr; m->rowptr_rows = 0; m->max_row_blocks = -1;
-    m->rm_reject_keys = nullptr; m->rm_reject_blocks = 0;
+    m->rm_partner_keys = nullptr; m->rm_partner_blocks = 0; m->rm_partner_mode = 0;
     pool_free(m->spmv_chunks); m->spmv_chunks = nullptr; m->spmv_num_chunks = 0; m->spmv_plan_long = 0; m->spmv_full_tiles = 0;
     pool_free(m->spmv_pos); m->spmv_pos = nullptr; m->spmv_tinfo = nullptr; m->spmv_eoff = nullptr; m->spmv_pos_base = 0; m->spmv_pos_count = 0; m->spmv_pos_tried = 0;
     pool_free(m->block_meta); m->block_meta = nullptr;
@@ -460,8 +460,11 @@ void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st)
     if (m->dtype == BMSP_F16 && m->block_num < (1ll << 25) && (!m->transposed || mac_mfma32_b_dense(m))) ensure_dense_tiles(m, st);
     // V15 block-MAC (tc_version 5): fp32 operands with tiles at least a quarter full are staged from a dense copy too (256 B per block)
     if (m->dtype == BMSP_F32 && m->nnz >= 16 * m->block_num && (uint64_t)m->block_num * 256 <= (4ull << 30)) ensure_dense_tiles(m, st);
-    // fp32 MFMA block-MAC (opt-in, BMSP_MAC_F32MFMA=1): the tiles in MFMA lane order (256 B per block)
-    if (m->dtype == BMSP_F32 && getenv("BMSP_MAC_F32MFMA") && mac_f32_mfma_usable(st)) ensure_lane_tiles(m, st);
+    // fp32 strip block-MAC (row-merge path) and the opt-in fp32 MFMA task-list kernel: the tiles in MFMA lane order (256 B per block)
+    if (m->dtype == BMSP_F32 && m->block_num < (1ll << 24) && mac_f32_mfma_usable(st)) ensure_lane_tiles(m, st);
+    // what decides whether a product takes the row-merge path: block-row pointer and maxima, "every stored value is finite"
+    ensure_row_stats(m, st);
+    if (m->dtype != BMSP_F64) ensure_finite_flag(m, st);
 }
 
 bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, const int *d_rows, const int *d_cols,

@@ -38,10 +38,11 @@ struct bmsp_matrix_s {
     // fp16 matrices: every tile expanded to 64 halves in position order (128 B per block), for the K = 32 MFMA block-MAC: built lazily
     void *dense_tiles = nullptr;
     void *lane_tiles = nullptr;   // fp32 matrices: tiles in the lane order of the fp32 MFMA block-MAC (256 B per block): built lazily
-    // SpGEMM row-merge path: the right operand (keys pointer, block count) with which this matrix's product did not fit the pass --
-    // the next product of the same pair goes straight to the pipeline
-    const void *rm_reject_keys = nullptr;
-    int64_t rm_reject_blocks = 0;
+    // SpGEMM row-merge paths: the right operand (keys pointer, block count) this matrix was last multiplied with and what that product
+    // turned out to need (1 strip mode, 2 task-list mode, 3 the pipeline) -- the next product of the pair goes there directly
+    const void *rm_partner_keys = nullptr;
+    int64_t rm_partner_blocks = 0;
+    int rm_partner_mode = 0;
     int values_finite = -1;       // fp16 operands of the strip block-MAC: 1 = no inf / NaN stored (-1 = not looked yet)
     // a row-panel view points into its parent
     int64_t view_block_begin = 0;
@@ -88,6 +89,7 @@ void ensure_row_stats(bmsp_matrix_s *m, hipStream_t st);
 void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st);
 void ensure_dense_tiles(bmsp_matrix_s *m, hipStream_t st);
 void ensure_lane_tiles(bmsp_matrix_s *m, hipStream_t st);
+void ensure_finite_flag(bmsp_matrix_s *m, hipStream_t st);
 bool mac_f32_mfma_usable(hipStream_t st);
 bool mac_mfma32_supported(const bmsp_matrix_s *A, const bmsp_matrix_s *B);
 bool mac_mfma32_b_dense(const bmsp_matrix_s *B);
@@ -104,6 +106,8 @@ uint32_t mac_strip_row_cap();
 void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);
 bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, uint32_t row_cap,
                        uint64_t *surviving, hipStream_t st);
+bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, DevBuf<uint64_t> &tasks,
+                       DevBuf<uint32_t> &task_begin, DevBuf<uint32_t> &c_of_wave, uint64_t *n_tasks, hipStream_t st);
 void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st);
 void matrix_to_coo_device_split(bmsp_matrix_s *m, int *d_rows, int *d_cols, double *d_vals, hipStream_t st);
 void matrix_to_csr_device(bmsp_matrix_s *m, int *d_row_offsets, int *d_cols, double *d_vals, hipStream_t st);

@@ -37,26 +37,123 @@ struct RowMergeArgs {
     uint32_t *overflow;
 };
 
+// chunk of 64 A tiles of the block-row being walked
+struct ChunkLds {
+    uint32_t abeg[64];   // first tile of B's block-row k
+    uint32_t aend[64];   // ... and one past its last
+    uint64_t abmp[64];
+};
+
 struct alignas(16) RowLds {
     uint32_t hk[kHash];  // block column; kEmpty = free
     uint64_t hb[kHash];  // OR of the tile-product bitmaps
-    uint32_t abeg[64];   // chunk of 64 A tiles: first tile of B's block-row k
-    uint32_t aend[64];   //                      ... and one past its last
-    uint64_t abmp[64];
+    ChunkLds ch;
 };  // 7 KB per wave: five workgroups per CU
+
+struct WalkArgs {
+    const uint64_t *a_keys, *a_bmps;
+    const uint64_t *b_keys, *b_bmps;
+    const uint32_t *b_rowptr;
+    uint32_t b_block_rows;
+};
+
+// Walks the candidate pairs of the A tiles [a0, a1) (one block-row of A).  64 / LPT A tiles at a time, LPT lanes each: the lanes of a
+// group walk B's block-row k of their tile LPT tiles per step (the words of the next step are requested before the current ones are
+// used).  step(live, a, t, j, abm, bbm) is called by the whole wave once per step -- live: this lane holds a candidate (A tile a, B
+// tile t of block column j, their bitmaps) -- and returns false (wave-uniformly) to stop the walk.  LPT = 64: one A tile at a time, i.e.
+// the candidates arrive in ascending A tile.
+template <int LPT = 16, typename Step>
+__device__ __forceinline__ bool walk_row(const WalkArgs &g, ChunkLds &L, uint32_t a0, uint32_t a1, int lane, Step step)
+{
+    constexpr uint32_t GROUPS = 64 / LPT;
+    struct Cur {
+        uint32_t u, t, end, j;
+        uint64_t abm, bbm;
+        bool valid;  // (wave-uniform) false: past the chunk's last step
+    };
+    for (uint32_t base = a0; base < a1; base += 64) {
+        const uint32_t a = base + (uint32_t)lane;
+        const bool on = a < a1;
+        const uint32_t k = on ? key_col(g.a_keys[a]) : 0u;
+        uint32_t bb = 0, be = 0;
+        if (on && k < g.b_block_rows) { bb = g.b_rowptr[k]; be = g.b_rowptr[k + 1]; }
+        __builtin_amdgcn_wave_barrier();
+        L.abeg[lane] = bb; L.aend[lane] = be; L.abmp[lane] = on ? g.a_bmps[a] : 0ull;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t na = min(64u, a1 - base);
+        uint32_t g4 = 0;  // group of the LAST step requested
+        // the first step of the group of A tiles that starts at g4 (its words requested here)
+        auto enter = [&]() {
+            Cur c;
+            c.valid = true;
+            c.u = g4 + (uint32_t)lane / (uint32_t)LPT;
+            c.end = c.u < na ? L.aend[c.u] : 0u;
+            c.abm = L.abmp[min(c.u, 63u)];
+            c.t = (c.u < na ? L.abeg[c.u] : 0u) + (uint32_t)lane % (uint32_t)LPT;
+            c.j = 0; c.bbm = 0;
+            if (c.t < c.end) { c.j = key_col(g.b_keys[c.t]); c.bbm = g.b_bmps[c.t]; }
+            return c;
+        };
+        // the step after c: the group's next LPT tiles, or the first step of the next group
+        auto after = [&](const Cur &c) {
+            Cur n = c;
+            if (!c.valid) return n;
+            if (__any(c.t + (uint32_t)LPT < c.end)) {
+                n.t = c.t + (uint32_t)LPT;
+                n.j = 0; n.bbm = 0;
+                if (n.t < n.end) { n.j = key_col(g.b_keys[n.t]); n.bbm = g.b_bmps[n.t]; }
+            } else {
+                g4 += GROUPS;
+                if (g4 < na) n = enter();
+                else n.valid = false;
+            }
+            return n;
+        };
+        // four steps in flight: a step's words have three steps' time to arrive (one step ahead measured 892 us for the cage-like fill
+        // pass at 12 waves per CU)
+        Cur q0 = enter(), q1 = after(q0), q2 = after(q1), q3 = after(q2);
+        while (q0.valid) {
+            if (__any(q0.t < q0.end)) {
+                if (!step(q0.t < q0.end, base + q0.u, q0.t, q0.j, q0.abm, q0.bbm)) return false;
+            }
+            q0 = q1; q1 = q2; q2 = q3; q3 = after(q3);
+        }
+    }
+    return true;
+}
+
+// insert block column j into the open-addressing table hk (kEmpty = free); returns the slot, fresh = this call claimed it
+template <int BITS = kHashBits>
+__device__ __forceinline__ uint32_t hash_insert(uint32_t *hk, uint32_t j, bool &fresh)
+{
+    uint32_t slot = (j * 0x9E3779B1u) >> (32 - BITS);
+    for (;;) {
+        const uint32_t old = atomicCAS(&hk[slot], kEmpty, j);
+        if (old == kEmpty || old == j) { fresh = old == kEmpty; return slot; }
+        slot = (slot + 1u) & ((1u << BITS) - 1u);
+    }
+}
+// the slot of a column that is in the table
+template <int BITS>
+__device__ __forceinline__ uint32_t hash_find(const uint32_t *hk, uint32_t j)
+{
+    uint32_t slot = (j * 0x9E3779B1u) >> (32 - BITS);
+    while (hk[slot] != j) slot = (slot + 1u) & ((1u << BITS) - 1u);
+    return slot;
+}
+
+__device__ __forceinline__ uint32_t xcd_order(uint32_t b, uint32_t G)
+{  // the workgroups of one XCD take a contiguous eighth of the block-rows (neighbouring rows read the same block-rows of B)
+    const uint32_t q = G / 8, rm = G % 8, x = b % 8;
+    return (x < rm ? x * (q + 1) : rm * (q + 1) + (x - rm) * q) + b / 8;
+}
 
 __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArgs g)
 {
     __shared__ RowLds lds_all[4];
     const int w = wave_id(), lane = lane_id();
     RowLds &S = lds_all[w];
-    // XCD-aware order: the workgroups of one XCD take a contiguous eighth of the block-rows (neighbouring rows read the same block-rows of B)
-    uint32_t wg;
-    {
-        const uint32_t G = gridDim.x, q = G / 8, rm = G % 8, x = blockIdx.x % 8;
-        wg = (x < rm ? x * (q + 1) : rm * (q + 1) + (x - rm) * q) + blockIdx.x / 8;
-    }
-    const uint32_t row = wg * 4 + (uint32_t)w;
+    const uint32_t row = xcd_order(blockIdx.x, gridDim.x) * 4 + (uint32_t)w;
     if (row >= g.block_rows) return;
     const uint32_t a0 = g.a_rowptr[row], a1 = g.a_rowptr[row + 1];
     // (a block-row beyond the cap makes the whole pass void: the waves that start after it was seen leave at once)
@@ -67,57 +164,22 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
     for (uint32_t s = (uint32_t)lane; s < (uint32_t)kHash; s += 64) { S.hk[s] = kEmpty; S.hb[s] = 0ull; }
     uint32_t n = 0;       // distinct columns so far (wave-uniform)
     uint32_t surv = 0;    // this lane's surviving pairs
-    bool over = false;
-    for (uint32_t base = a0; base < a1 && !over; base += 64) {
-        const uint32_t a = base + (uint32_t)lane;
-        const bool on = a < a1;
-        const uint32_t k = on ? key_col(g.a_keys[a]) : 0u;
-        uint32_t bb = 0, be = 0;
-        if (on && k < g.b_block_rows) { bb = g.b_rowptr[k]; be = g.b_rowptr[k + 1]; }
-        __builtin_amdgcn_wave_barrier();
-        S.abeg[lane] = bb; S.aend[lane] = be; S.abmp[lane] = on ? g.a_bmps[a] : 0ull;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t na = min(64u, a1 - base);
-        // four A tiles at a time, 16 lanes each: the lanes of a group walk B's block-row k of their tile 16 tiles per step (the words of
-        // the next step are requested before the current ones are used)
-        for (uint32_t g4 = 0; g4 < na && !over; g4 += 4) {
-            const uint32_t u = g4 + (uint32_t)(lane >> 4);
-            const uint32_t end = u < na ? S.aend[u] : 0u;
-            const uint64_t abm = S.abmp[min(u, 63u)];
-            uint32_t t = (u < na ? S.abeg[u] : 0u) + (uint32_t)(lane & 15);
-            uint32_t j = 0;
-            uint64_t bbm = 0;
-            if (t < end) { j = key_col(g.b_keys[t]); bbm = g.b_bmps[t]; }
-            while (__any(t < end)) {
-                if (n > g.row_cap) { over = true; break; }
-                const bool live = t < end;
-                const uint32_t tn = t + 16u;
-                uint32_t jn = 0;
-                uint64_t bn = 0;
-                if (tn < end) { jn = key_col(g.b_keys[tn]); bn = g.b_bmps[tn]; }
-                const bool keep = live && !tile_product_empty(abm, bbm);  // multiplication_checker (:742-757)
-                surv += keep ? 1u : 0u;
-                bool fresh = false;
-                if (keep) {
-                    // bmp_calculator (:787-810); two full tiles: a full one
-                    const uint64_t prod = (abm & bbm) == ~0ull ? ~0ull : tile_product_bmp(abm, bbm);
-                    uint32_t slot = (j * 0x9E3779B1u) >> (32 - kHashBits);
-                    for (;;) {
-                        const uint32_t old = atomicCAS(&S.hk[slot], kEmpty, j);
-                        if (old == kEmpty || old == j) {
-                            fresh = old == kEmpty;
-                            atomicOr((unsigned long long *)&S.hb[slot], (unsigned long long)prod);
-                            break;
-                        }
-                        slot = (slot + 1u) & (uint32_t)(kHash - 1);
-                    }
-                }
-                n += (uint32_t)__popcll(__ballot(fresh));
-                t = tn; j = jn; bbm = bn;
-            }
+    const WalkArgs wa{g.a_keys, g.a_bmps, g.b_keys, g.b_bmps, g.b_rowptr, g.b_block_rows};
+    const bool done = walk_row(wa, S.ch, a0, a1, lane, [&](bool live, uint32_t, uint32_t, uint32_t j, uint64_t abm, uint64_t bbm) {
+        if (n > g.row_cap) return false;
+        const bool keep = live && !tile_product_empty(abm, bbm);  // multiplication_checker (:742-757)
+        surv += keep ? 1u : 0u;
+        bool fresh = false;
+        if (keep) {
+            // bmp_calculator (:787-810); two full tiles: a full one
+            const uint64_t prod = (abm & bbm) == ~0ull ? ~0ull : tile_product_bmp(abm, bbm);
+            const uint32_t slot = hash_insert(S.hk, j, fresh);
+            atomicOr((unsigned long long *)&S.hb[slot], (unsigned long long)prod);
         }
-    }
-    if (over || n > g.row_cap) {
+        n += (uint32_t)__popcll(__ballot(fresh));
+        return true;
+    });
+    if (!done || n > g.row_cap) {
         if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; atomicOr(g.overflow, 1u); }
         return;
     }
@@ -158,6 +220,212 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
     surv = wave_sum(surv);
     if (lane == 0) { g.cnt[row] = m; g.surv[row] = surv; }  // (per-row results: one atomic pair per wave would serialise at the memory side)
 }
+
+// ---- row-merge WITH a task list: block-rows of C of up to kTlCap tiles, for the task-list block-MAC kernels ------------------------------
+// Build pass, one wave per block-row of A, ONE walk over its candidate pairs: every surviving pair enters the column table (its C
+// tile's task count with it) and is parked, with its tile-product bitmap, in walk order in the block-row's own stretch of scratch (the
+// stretch of its candidate pairs, known from T_2's scan: no offsets to wait for).  Then, still row-local: the columns are ranked (C's
+// key order), the task counts scanned in rank order, every parked pair put at (first task of its C tile + the count it found there), the
+// products ORed into the tiles' bitmaps.  After two scans over the block-rows (C's block-row
+// pointer, first task of every block-row) a copy pass moves keys, bitmaps, task ranges and tasks from the stretches to their places.
+// (A first form -- count pass, then a fill pass that walked the candidates twice more -- measured 97 + 540 us on the cage-like product,
+// against 660 us for the pipeline's five stages: three walks of 21 M candidate pairs cost what the pipeline costs.)
+constexpr int kTlBits = 10;
+constexpr int kTlHash = 1 << kTlBits;
+constexpr uint32_t kTlCap = 896;  // distinct C tiles per block-row (+ 63)
+
+struct TaskListArgs {
+    WalkArgs w;
+    const uint32_t *a_rowptr;
+    const uint64_t *first_pos;  // T_2: candidate pairs in front of every A tile
+    uint32_t block_rows;
+    uint32_t *cnt, *surv, *overflow;
+    // scratch, indexed from the block-row's first candidate pair
+    uint64_t *s_surv;   // surviving pairs in walk order: slot << 48 | (A tile - the row's first) << 32 | B tile
+    uint64_t *s_prod;   // ... their tile products
+    uint16_t *s_ord;    // ... and how many earlier pairs went to the same C tile
+    uint64_t *s_tasks;  // the tasks in final order
+    uint32_t *s_cols;   // by rank: C's block columns,
+    uint32_t *s_begin;  //          first task of the C tile relative to the block-row's first,
+    unsigned long long *s_bmps;  //  C's bitmaps
+    // copy pass
+    const uint32_t *c_rowptr, *row_task0;
+    uint64_t *c_keys, *c_bmps;
+    uint32_t *task_begin;
+    uint64_t *tasks;
+};
+
+struct alignas(16) BuildLds {
+    uint32_t hk[kTlHash];       // block column; kEmpty = free
+    uint32_t tc[kTlHash / 2];   // two 16-bit fields per word (slot s: word s >> 1, half s & 1): tasks of the slot's C tile
+    uint16_t rk[kTlHash];       // rank of the slot's column among the block-row's columns = C tile relative to the block-row's first
+    uint32_t list[kTlHash];     // ranking: bit words + prefix counts of a window of columns; then the tiles' task counts in rank order and their scan
+    ChunkLds ch;
+};  // 13 KB per wave
+
+
+__global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g)
+{
+    __shared__ BuildLds lds_all[4];
+    const int w = wave_id(), lane = lane_id();
+    BuildLds &S = lds_all[w];
+    const uint32_t row = xcd_order(blockIdx.x, gridDim.x) * 4 + (uint32_t)w;
+    if (row >= g.block_rows) return;
+    const uint32_t a0 = g.a_rowptr[row], a1 = g.a_rowptr[row + 1];
+    if (a0 == a1 || __builtin_nontemporal_load(g.overflow) != 0u) {
+        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; }
+        return;
+    }
+    const uint64_t off = g.first_pos[a0];
+    for (uint32_t s = (uint32_t)lane; s < (uint32_t)kTlHash; s += 64) S.hk[s] = kEmpty;
+    for (uint32_t s = (uint32_t)lane; s < (uint32_t)kTlHash / 2; s += 64) S.tc[s] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    // ---- the walk: table, task counts, surviving pairs and their products parked in walk order ----
+    uint32_t n = 0, ns = 0;  // distinct columns, surviving pairs so far (wave-uniform)
+    bool done = a1 - a0 <= 65535u;
+    // (one A tile at a time: the columns of one block-row of B are distinct, so the count a pair finds at its C tile is the number of that
+    // tile's tasks from smaller A tiles -- its place inside the tile, in V15's summation order (:269-273))
+    if (done) done = walk_row<64>(g.w, S.ch, a0, a1, lane, [&](bool live, uint32_t a, uint32_t t, uint32_t j, uint64_t abm, uint64_t bbm) {
+        if (n > kTlCap || ns + 64u > 65535u) return false;  // (task offsets inside a block-row are kept in 16 bits)
+        const bool keep = live && !tile_product_empty(abm, bbm);  // multiplication_checker (:742-757)
+        const uint64_t bal = __ballot(keep);
+        bool fresh = false;
+        if (keep) {
+            const uint32_t slot = hash_insert<kTlBits>(S.hk, j, fresh);
+            const uint32_t old = atomicAdd(&S.tc[slot >> 1], 1u << (16u * (slot & 1u)));
+            const uint32_t k = ns + (uint32_t)__popcll(bal & lanemask_lt());
+            g.s_surv[off + k] = ((uint64_t)slot << 48) | ((uint64_t)(a - a0) << 32) | (uint64_t)t;
+            g.s_prod[off + k] = (abm & bbm) == ~0ull ? ~0ull : tile_product_bmp(abm, bbm);  // bmp_calculator (:787-810); two full tiles: a full one
+            g.s_ord[off + k] = (uint16_t)((old >> (16u * (slot & 1u))) & 0xffffu);
+        }
+        ns += (uint32_t)__popcll(bal);
+        n += (uint32_t)__popcll(__ballot(fresh));
+        return true;
+    });
+    if (!done || n > kTlCap) {
+        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; atomicOr(g.overflow, 1u); }
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- rank of every column among the block-row's columns (= its C tile).  Counting sort by bitmap: the columns of a window of kWin
+    //      block columns set their bit, the words' popcounts are scanned, rank = bits below.  (Counting the smaller columns per column,
+    //      n^2 / 4 16-byte LDS reads per block-row, measured 390 us on the cage-like product; this form 55 us.) ----
+    constexpr uint32_t kWin = 24576, kWinWords = kWin / 64;  // 3 KB of bit words + 768 B of prefix counts inside `list`
+    uint64_t *const bw = (uint64_t *)S.list;
+    uint16_t *const bp = (uint16_t *)(S.list + 2 * kWinWords);
+    uint32_t jmin = kEmpty, jmax = 0;
+    for (uint32_t r = 0; r < (uint32_t)kTlHash; r += 64) {
+        const uint32_t key = S.hk[r + (uint32_t)lane];
+        if (key != kEmpty) { jmin = min(jmin, key); jmax = max(jmax, key); }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        jmin = min(jmin, (uint32_t)__shfl_xor((int)jmin, d, kWave));
+        jmax = max(jmax, (uint32_t)__shfl_xor((int)jmax, d, kWave));
+    }
+    uint32_t m = 0;  // columns ranked so far = columns below the current window
+    for (uint32_t lo = jmin; n; lo += kWin) {
+        for (uint32_t wd = (uint32_t)lane; wd < kWinWords; wd += 64) bw[wd] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t r = 0; r < (uint32_t)kTlHash; r += 64) {
+            const uint32_t key = S.hk[r + (uint32_t)lane];
+            if (key != kEmpty && key - lo < kWin) atomicOr((unsigned long long *)&bw[(key - lo) >> 6], 1ull << ((key - lo) & 63u));
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t carry = 0;
+        for (uint32_t w0 = 0; w0 < kWinWords; w0 += 64) {
+            const uint32_t c = (uint32_t)__popcll(bw[w0 + (uint32_t)lane]);
+            const uint32_t inc = wave_inclusive_sum(c);
+            bp[w0 + (uint32_t)lane] = (uint16_t)(carry + inc - c);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t r = 0; r < (uint32_t)kTlHash; r += 64) {
+            const uint32_t s = r + (uint32_t)lane;
+            const uint32_t key = S.hk[s];
+            if (key != kEmpty && key - lo < kWin) {
+                const uint32_t wd = (key - lo) >> 6, bit = (key - lo) & 63u;
+                const uint32_t rank = m + (uint32_t)bp[wd] + (uint32_t)__popcll(bw[wd] & ((1ull << bit) - 1ull));
+                S.rk[s] = (uint16_t)rank;
+                g.s_cols[off + rank] = key;
+            }
+        }
+        m += carry;
+        __builtin_amdgcn_wave_barrier();
+        if (jmax - lo < kWin) break;
+    }
+    // ---- task counts in rank order, their exclusive scan = first task of every C tile relative to the block-row's first ----
+    for (uint32_t r = 0; r < (uint32_t)kTlHash; r += 64) {
+        const uint32_t s = r + (uint32_t)lane;
+        if (S.hk[s] != kEmpty) S.list[S.rk[s]] = (S.tc[s >> 1] >> (16u * (s & 1u))) & 0xffffu;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t carry = 0;
+    for (uint32_t p0 = 0; p0 < m; p0 += 64) {
+        const uint32_t p = p0 + (uint32_t)lane;
+        const uint32_t v = p < m ? S.list[p] : 0u;
+        const uint32_t inc = wave_inclusive_sum(v);
+        if (p < m) {
+            S.list[p] = carry + inc - v;
+            g.s_begin[off + p] = carry + inc - v;
+            g.s_bmps[off + p] = 0ull;
+        }
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the parked pairs and the zeroed bitmaps are written before other lanes of this wave read / OR into them: a workgroup-scope fence (the
+    // wave's own CU: a wait for the stores; an agent-scope fence writes the XCD's L2 back -- 1.25 ms for this kernel on the cage-like product)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- the parked pairs to their places, their products into the tiles' bitmaps ----
+    for (uint32_t k0 = 0; k0 < ns; k0 += 64) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        if (k < ns) {
+            const uint64_t e = g.s_surv[off + k], pr = g.s_prod[off + k];
+            const uint32_t ord = (uint32_t)g.s_ord[off + k];
+            const uint32_t rank = (uint32_t)S.rk[(uint32_t)(e >> 48)];
+            g.s_tasks[off + S.list[rank] + ord] = ((uint64_t)(a0 + (uint32_t)((e >> 32) & 0xffffu)) << 32) | (e & 0xffffffffull);
+            atomicOr(&g.s_bmps[off + rank], (unsigned long long)pr);
+        }
+    }
+    if (lane == 0) { g.cnt[row] = m; g.surv[row] = ns; }
+}
+
+// stretches -> C's own arrays and the task list: one wave per block-row
+__global__ __launch_bounds__(kThreads) void rowmerge_copy_kernel(TaskListArgs g)
+{
+    const int lane = lane_id();
+    const uint32_t row = xcd_order(blockIdx.x, gridDim.x) * 4 + (uint32_t)wave_id();
+    if (row >= g.block_rows) return;
+    const uint32_t c0 = g.c_rowptr[row], m = g.c_rowptr[row + 1] - c0;
+    if (m == 0) return;
+    const uint32_t t0 = g.row_task0[row], ns = g.row_task0[row + 1] - t0;
+    const uint64_t off = g.first_pos[g.a_rowptr[row]];
+    for (uint32_t r = (uint32_t)lane; r < m; r += 64) {
+        g.c_keys[c0 + r] = key_make(row, g.s_cols[off + r]);
+        g.c_bmps[c0 + r] = (uint64_t)g.s_bmps[off + r];
+        g.task_begin[c0 + r] = t0 + g.s_begin[off + r];
+    }
+    for (uint32_t k = (uint32_t)lane; k < ns; k += 64) g.tasks[t0 + k] = g.s_tasks[off + k];
+}
+
+// C tile of task 64 w (what the task-list block-MAC kernels index per 64 tasks)
+struct COfWave {
+    const uint32_t *task_begin;
+    uint32_t c_size;
+    uint32_t *out;
+    __device__ void operator()(uint64_t w) const
+    {
+        const uint32_t t = (uint32_t)(w * 64);
+        uint32_t lo = 0, hi = c_size - 1u;  // last c with task_begin[c] <= t
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (task_begin[mid] <= t) lo = mid;
+            else hi = mid - 1u;
+        }
+        out[w] = lo;
+    }
+};
 
 // scratch slots of block-row i: its candidate pairs (T_2's scan), capped by what the kernel accepts
 struct RowSlotsIn {
@@ -266,6 +534,88 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
         hipLaunchKernelGGL(rowmerge_emit_kernel, dim3((uint32_t)((rows + 3) / 4)), dim3(kThreads), 0, st, tmp_off.p, t_cols.p, t_bmps.p, c_rowptr,
                            (uint32_t)rows, C->keys, C->bmps);
         BMSP_CHECK_LAUNCH();
+    }
+    return true;
+}
+
+namespace {
+struct PublishTaskStats {
+    const unsigned long long *acc;  // [1] most C tiles in a block-row, [2] overflow flag
+    uint64_t *h_max_over;
+    __device__ void operator()(uint64_t) const { *h_max_over = ((uint64_t)(uint32_t)acc[2] << 32) | (uint64_t)acc[1]; }
+};
+struct SetU32 {
+    uint32_t *p;
+    uint32_t v;
+    __device__ void operator()(uint64_t) const { *p = v; }
+};
+}  // namespace
+
+// C's structure AND the sorted task list of A x B by the build pass and the copy pass.  first_pos = T_2's exclusive scan of the fan-out
+// per A tile.  false: some block-row of C holds more tiles (or a block-row more than 65535 surviving pairs) than the pass accepts --
+// nothing of C was allocated.  true: C->keys / bmps / rowptr / block_num / max_row_blocks are set; tasks = the surviving pairs
+// ((A tile << 32) | B tile) grouped by C tile in C's key order, inside a tile in ascending A tile; task_begin[c] = first task of C tile
+// c (c_size + 1 entries); c_of_wave[w] = C tile of task 64 w.
+bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, DevBuf<uint64_t> &tasks,
+                       DevBuf<uint32_t> &task_begin, DevBuf<uint32_t> &c_of_wave, uint64_t *n_tasks_out, hipStream_t st)
+{
+    const uint64_t rows = (uint64_t)A->num_block_rows();
+    if (rows == 0 || rows >= (1ull << 31) || total == 0 || total >= (1ull << 32)) return false;
+    if (total * 42 > (16ull << 30)) return false;  // scratch: 42 bytes per candidate pair
+    ensure_rowptr(A, st);
+    ensure_rowptr(B, st);
+    DevBuf<uint32_t> cnt(rows + 1), surv_row(rows + 1), row_task0(rows + 1), s_cols(total), s_begin(total);
+    DevBuf<uint64_t> s_surv(total), s_prod(total), s_tasks(total), s_bmps(total);
+    DevBuf<uint16_t> s_ord(total);
+    DevBuf<unsigned long long> acc(3);  // [1] most C tiles in a block-row, [2] overflow flag
+    BMSP_HIP(hipMemsetAsync(acc.p, 0, 24, st));
+    TaskListArgs g{};
+    g.w = WalkArgs{A->keys, A->bmps, B->keys, B->bmps, B->rowptr, (uint32_t)B->num_block_rows()};
+    g.a_rowptr = A->rowptr; g.first_pos = first_pos; g.block_rows = (uint32_t)rows;
+    g.cnt = cnt.p; g.surv = surv_row.p; g.overflow = (uint32_t *)(acc.p + 2);
+    g.s_surv = s_surv.p; g.s_prod = s_prod.p; g.s_ord = s_ord.p; g.s_tasks = s_tasks.p; g.s_cols = s_cols.p; g.s_begin = s_begin.p;
+    g.s_bmps = (unsigned long long *)s_bmps.p;
+    const dim3 grid((uint32_t)((rows + 3) / 4));
+    hipLaunchKernelGGL(rowmerge_build_kernel, grid, dim3(kThreads), 0, st, g);
+    BMSP_CHECK_LAUNCH();
+    uint32_t *c_rowptr = (uint32_t *)pool_alloc(sizeof(uint32_t) * (size_t)(rows + 1));
+    HostScalar<uint32_t> c_size_h, n_tasks_h;
+    HostScalar<uint64_t> mo_h;
+    uint32_t c_size = 0, n_tasks = 0;
+    uint64_t mo = 0;
+    try {
+        device_exclusive_scan<uint32_t>(CntIn{cnt.p, rows}, PtrOutTotal<uint32_t>{c_rowptr, rows, c_size_h.dev()}, rows + 1, st);
+        device_exclusive_scan<uint32_t>(CntIn{surv_row.p, rows}, PtrOutTotal<uint32_t>{row_task0.p, rows, n_tasks_h.dev()}, rows + 1, st);
+        device_max_sum(CntSurvIn{cnt.p}, rows, acc.p + 1, (unsigned long long *)nullptr, st);
+        device_for_each(PublishTaskStats{acc.p, mo_h.dev()}, 1, st);
+        c_size = c_size_h.wait(st);
+        n_tasks = n_tasks_h.wait(st);
+        mo = mo_h.wait(st);
+    } catch (...) {
+        pool_free(c_rowptr);
+        throw;
+    }
+    if (mo >> 32) {
+        pool_free(c_rowptr);
+        return false;
+    }
+    C->block_num = c_size;
+    C->rowptr = c_rowptr;
+    C->rowptr_rows = (int64_t)rows;
+    C->max_row_blocks = (int64_t)(uint32_t)mo;
+    C->keys = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
+    C->bmps = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
+    tasks.alloc(n_tasks);
+    task_begin.alloc((size_t)c_size + 1);
+    c_of_wave.alloc((size_t)n_tasks / 64 + 1);
+    *n_tasks_out = n_tasks;
+    device_for_each(SetU32{task_begin.p + c_size, n_tasks}, 1, st);
+    if (c_size) {
+        g.c_rowptr = c_rowptr; g.row_task0 = row_task0.p;
+        g.c_keys = C->keys; g.c_bmps = C->bmps; g.task_begin = task_begin.p; g.tasks = tasks.p;
+        hipLaunchKernelGGL(rowmerge_copy_kernel, grid, dim3(kThreads), 0, st, g);
+        BMSP_CHECK_LAUNCH();
+        device_for_each(COfWave{task_begin.p, c_size, c_of_wave.p}, ((uint64_t)n_tasks + 63) / 64, st);
     }
     return true;
 }

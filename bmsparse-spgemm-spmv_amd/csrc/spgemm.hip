@@ -994,27 +994,40 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         *Cout = C.release();
     };
 
-    // Row-merge path (rowmerge.hip): the symbolic stages in one LDS-resident pass per block-row, the numeric stage by the strip kernel,
-    // no task list.  Taken when the sort mode is left to the library, the operands fit the strip kernel and every block-row of C fits the
-    // pass; a product that turns out not to fit costs the pass (FEM-like: ROWMERGE_US us) and continues below.  BMSP_SPGEMM_ROWMERGE=0/1
-    // switches it off / takes it whenever it fits.
+    // Row-merge paths (rowmerge.hip): C's structure formed block-row by block-row in LDS instead of expand - sort - compress.  Taken when
+    // the sort mode is left to the library.  (1) Strip mode -- one pass, no task list, numeric stage by the strip kernel -- when the
+    // operands fit that kernel and every block-row of C holds at most mac_strip_row_cap() tiles; (2) task-list mode -- a count pass and a
+    // fill pass that also writes the sorted task list, numeric stage by the task-list kernels of the tc_version -- for block-rows of C
+    // of up to ~900 tiles; (3) the pipeline below otherwise (hub rows).  What a pair of operands turned out to need is remembered on A's
+    // handle, so that only the first product of a pair pays for a pass that did not fit (cage-like: 280 us).  BMSP_SPGEMM_ROWMERGE=0
+    // switches both off, =1 takes them under an explicit sort mode too, =2 skips strip mode.
+    uint64_t n_tasks = 0;
+    uint32_t c_size = 0;
+    DevBuf<uint64_t> k0, k1, v0, v1, rm_tasks;
+    DevBuf<uint32_t> task_begin, c_of_wave;
+    const uint64_t *tasks_sorted = nullptr;
+    bool have_tasks = false;
     {
         const char *rme = getenv("BMSP_SPGEMM_ROWMERGE");
-        const bool rm_force = rme && rme[0] == '1', rm_off = rme && rme[0] == '0';
+        const bool rm_force = rme && rme[0] != '0', rm_off = rme && rme[0] == '0', rm_no_strip = rme && rme[0] == '2';
+        const bool rm_on = !rm_off && total && (mode == BMSP_SORT_AUTO || rm_force);
+        const bool known = A->rm_partner_keys == (const void *)B->keys && A->rm_partner_blocks == B->block_num;
+        const int hint = known ? A->rm_partner_mode : 0;  // 0 unknown, 1 strip mode fits, 2 task-list mode, 3 pipeline
+        auto remember = [&](int m) { A->rm_partner_keys = B->keys; A->rm_partner_blocks = B->block_num; A->rm_partner_mode = m; };
         // numeric stages that work from C's structure alone: the K = 32 MFMA strip kernel (tc_version 4, fp16) and its fp32 form (V15's
         // summation order on v_mfma_f32_16x16x4_f32: any tc_version, as fp32 operands always take V15's numerics)
         const bool rm_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || (A->dtype == BMSP_F32 && !getenv("BMSP_MAC_VALU_DENSE") && !getenv("BMSP_MAC_F32MFMA"));
-        bool try_rm = !rm_off && total && rm_numeric && (mode == BMSP_SORT_AUTO || rm_force) &&
-                      !(A->rm_reject_keys == (const void *)B->keys && A->rm_reject_blocks == B->block_num);
-        if (try_rm) {
+        bool try_strip = rm_on && rm_numeric && !rm_no_strip && hint != 2 && hint != 3;
+        if (try_strip) {
             const char *sf = getenv("BMSP_MAC_STRIP");
-            try_rm = !(sf && sf[0] == '0') && mac_strip_operands_ok(A, B, st);
+            try_strip = !(sf && sf[0] == '0') && mac_strip_operands_ok(A, B, st);
         }
-        if (try_rm) {
+        if (try_strip) {
             uint64_t surv = 0;
             if (rowmerge_symbolic(A, B, C.get(), first_pos.p, total, mac_strip_row_cap(), &surv, st)) {
                 if (C->block_num == 0 || mac_strip_fits_c(C.get(), st)) {
                     tm.mark(3);
+                    remember(1);
                     S->surviving_tasks = (int64_t)surv;
                     S->bmp_reduction = (int64_t)(total - surv);
                     S->sort_path = BMSP_SORT_PATH_ROWMERGE;
@@ -1029,15 +1042,32 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
                     finish();
                     return;
                 }
-                // C exists but a strip of it exceeds the kernel's column list: drop it and build the task list
+                // C exists but a strip of it exceeds the kernel's column list: drop it
                 pool_free(C->keys); pool_free(C->bmps); pool_free(C->rowptr);
                 C->keys = nullptr; C->bmps = nullptr; C->rowptr = nullptr; C->rowptr_rows = 0; C->max_row_blocks = -1; C->block_num = 0;
             }
-            A->rm_reject_keys = B->keys; A->rm_reject_blocks = B->block_num;  // (a pass that ran and did not fit: not again for this pair)
             tm.mark(-1);
+        }
+        if (rm_on && hint != 3) {
+            if (rowmerge_tasklist(A, B, C.get(), first_pos.p, total, rm_tasks, task_begin, c_of_wave, &n_tasks, st)) {
+                remember(2);
+                have_tasks = true;
+                tasks_sorted = rm_tasks.p;
+                c_size = (uint32_t)C->block_num;
+                tm.mark(3);
+                S->surviving_tasks = (int64_t)n_tasks;
+                S->bmp_reduction = (int64_t)(total - n_tasks);
+                S->sort_path = BMSP_SORT_PATH_ROWMERGE;
+                finish_structure();
+                tm.mark(9);
+            } else {
+                remember(3);
+                tm.mark(-1);
+            }
         }
     }
 
+    if (!have_tasks) {
     // T_3 + T_4: expansion fused with the bitmap filter
     const int jbits = std::max(1, ceil_log2_u64((uint64_t)B->num_block_cols()));
     const int ibits = std::max(1, ceil_log2_u64((uint64_t)A->num_block_rows()));
@@ -1046,8 +1076,6 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     const uint32_t tiles = (uint32_t)((total + tile_e - 1) / tile_e);
     ExpandArgs ea{first_pos.p, A->keys, A->bmps, B->keys, B->bmps, B->rowptr, n_a, total, jbits};
     DevBuf<uint32_t> tile_counts((size_t)tiles + 1);
-    uint64_t n_tasks = 0;
-    DevBuf<uint64_t> k0, k1, v0, v1;
     // The single-pass form (decoupled look-back, candidate-sized output) is kept as an option: measured on MI355X it costs what the
     // count + write pair costs (cage-like 224 vs 106 + 128 us, FEM-like 358 vs 147 + 210 us) and loses on small products (full-tile
     // banded 69 vs 49 us): a workgroup holds its slot through the look-back and the sixteen ordered block scans of the write.
@@ -1128,10 +1156,9 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     // task-sized scratch and C's own key array is cut to size once the block count is known (a counting scan first, as the
     // reference's reduce_by_key does internally, would read the sorted keys twice more).
     HostScalar<uint32_t> csize_h;
-    uint32_t c_size = 0;
     DevBuf<uint64_t> c_keys_scratch((size_t)n_tasks);
-    DevBuf<uint32_t> task_begin((size_t)n_tasks + 1);
-    DevBuf<uint32_t> c_of_wave((size_t)(n_tasks / 64 + 1));
+    task_begin.alloc((size_t)n_tasks + 1);
+    c_of_wave.alloc((size_t)(n_tasks / 64 + 1));
     if (n_tasks) {
         device_exclusive_scan<uint32_t>(KeyHead{kk.cur, n_tasks}, EmitCBlocks{kk.cur, n_tasks, jbits, c_keys_scratch.p, task_begin.p, c_of_wave.p, csize_h.dev()},
                                         n_tasks + 1, st);
@@ -1152,6 +1179,8 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     }
     finish_structure();
     tm.mark(9);
+    tasks_sorted = vv.cur;
+    }  // (expand - sort - compress)
 
     // T_7: block multiply-accumulate
     if (c_size) {
@@ -1168,30 +1197,30 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
                     launch_mac_strip(A, B, C.get(), st);
                     S->mac_variant = BMSP_MAC_STRIP;
                 } else {
-                    S->mac_variant = launch_mac_mfma32(vv.cur, n_tasks, task_begin.p, c_of_wave.p, A, B, C.get(), st);
+                    S->mac_variant = launch_mac_mfma32(tasks_sorted, n_tasks, task_begin.p, c_of_wave.p, A, B, C.get(), st);
                 }
             } else if (tc_version == 4 && pool_owns(A->values) && pool_owns(B->values) && A->block_num < (1ll << 28) && B->block_num < (1ll << 28)) {
                 ensure_block_meta(A, st);
                 ensure_block_meta(B, st);
                 uint32_t groups = (c_size + kGroupC - 1) / kGroupC;
                 uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
-                hipLaunchKernelGGL(block_mac_mfma_f16_group_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->block_meta,
+                hipLaunchKernelGGL(block_mac_mfma_f16_group_kernel, dim3(grid), dim3(kThreads), 0, st, tasks_sorted, task_begin.p, A->block_meta,
                                    (uint32_t)(A->block_num * 16), (const _Float16 *)A->values, B->block_meta, (uint32_t)(B->block_num * 16),
                                    (const _Float16 *)B->values, C->bmps, C->offsets, (float *)C->values, c_size, a_bytes + 16u, b_bytes + 16u);
             } else {
                 uint32_t groups = ((c_size + 1) / 2 + kPairsPerWave - 1) / kPairsPerWave;
                 uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
-                hipLaunchKernelGGL(block_mac_mfma_f16_kernel, dim3(grid), dim3(kThreads), 0, st, vv.cur, task_begin.p, A->bmps, A->offsets,
+                hipLaunchKernelGGL(block_mac_mfma_f16_kernel, dim3(grid), dim3(kThreads), 0, st, tasks_sorted, task_begin.p, A->bmps, A->offsets,
                                    (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
                                    (float *)C->values, c_size, a_bytes, b_bytes);
             }
             BMSP_CHECK_LAUNCH();
             S->mac_kernel = tc_version;
         } else {
-            if (A->dtype == BMSP_F32 && launch_mac_f32_mfma(vv.cur, n_tasks, task_begin.p, c_of_wave.p, A, B, C.get(), st)) S->mac_variant = BMSP_MAC_F32MFMA;
-            else if (A->dtype == BMSP_F32) launch_mac_valu<float>(vv.cur, task_begin.p, A, B, C.get(), st);
-            else if (A->dtype == BMSP_F16) launch_mac_valu<_Float16>(vv.cur, task_begin.p, A, B, C.get(), st);
-            else launch_mac_valu<double>(vv.cur, task_begin.p, A, B, C.get(), st);
+            if (A->dtype == BMSP_F32 && launch_mac_f32_mfma(tasks_sorted, n_tasks, task_begin.p, c_of_wave.p, A, B, C.get(), st)) S->mac_variant = BMSP_MAC_F32MFMA;
+            else if (A->dtype == BMSP_F32) launch_mac_valu<float>(tasks_sorted, task_begin.p, A, B, C.get(), st);
+            else if (A->dtype == BMSP_F16) launch_mac_valu<_Float16>(tasks_sorted, task_begin.p, A, B, C.get(), st);
+            else launch_mac_valu<double>(tasks_sorted, task_begin.p, A, B, C.get(), st);
             S->mac_kernel = 5;
         }
     }

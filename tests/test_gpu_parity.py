@@ -760,6 +760,40 @@ def test_spgemm_rowmerge_path(oracle, bmsp, monkeypatch, case, dtype):
     assert st2["sort_path"] == 0
 
 
+@pytest.mark.parametrize("case", ["banded64", "fem", "rect_ragged", "filtered_run", "empty_strips", "cage_wide"])
+@pytest.mark.parametrize("dtype,tc", [(1, 4), (0, 5), (1, 5), (2, 5), (1, 1)])
+def test_spgemm_rowmerge_task_list(oracle, bmsp, monkeypatch, case, dtype, tc):
+    """Task-list mode of the row-merge path (BMSP_SPGEMM_ROWMERGE=2 skips strip mode): a count pass and a fill pass form C's keys,
+    bitmaps AND the sorted task list per block-row in LDS; the block-MAC kernels of the tc_version run from it.  The list is the
+    pipeline's (C key order, ascending A tile inside a C tile), so every array of C equals the pipeline's bit for bit -- for every value
+    type and kernel -- and the oracle's within check_spgemm's terms.  cage_wide: block-rows of C beyond the strip kernel's capacity take
+    this mode without the switch."""
+    from pybmsp import gen
+    exact = False
+    if case == "cage_wide":
+        n, _, r, c, v = gen.cage_like(24000, per_row=10.0)  # up to 310 C tiles per block-row
+        A = Bc = (n, n, r, c, np.round(v * 64) / 64)
+    else:
+        A, Bc, exact = _strip_case(gen, oracle, case)
+        if Bc is None:
+            Bc = A
+        monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "2")
+    st = check_spgemm(oracle, bmsp, A, Bc, dtype, 0, tc, exact_expected=exact)
+    assert st["sort_path"] == 2 and st["mac_variant"] != 3, st
+    a = bmsp.BmSpMatrix.from_coo(*A, dtype=dtype)
+    b = bmsp.BmSpMatrix.from_coo(*Bc, transposed=True, dtype=dtype)
+    new, stn = bmsp.spgemm(a, b, tc_version=tc)
+    new2, _ = bmsp.spgemm(a, b, tc_version=tc)  # (the pair's mode is remembered on the handle: straight to the task-list passes)
+    assert stn["sort_path"] == 2
+    monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "0")
+    monkeypatch.setenv("BMSP_MAC_STRIP", "0")
+    old, sto = bmsp.spgemm(a, b, tc_version=tc)
+    assert sto["sort_path"] in (0, 1) and sto["mac_variant"] == stn["mac_variant"]
+    for x, y, z in zip(old.host_arrays(), new.host_arrays(), new2.host_arrays()):
+        np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(x, z)
+
+
 @pytest.mark.parametrize("case", ["rmat", "banded", "filtered", "rect"])
 def test_spgemm_single_pass_expansion(oracle, bmsp, monkeypatch, case):
     """BMSP_EXPAND_LOOKBACK: T_3 + T_4 as one decoupled look-back pass (survivors written at the running prefix of the earlier tiles);
