@@ -364,40 +364,32 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
                 const uint32_t a = S.ka[min(4 * cur.gi + (uint32_t)k4, (uint32_t)kKCap - 1u)][half_sel];
                 fa[k4] = __builtin_bit_cast(f32x2k_t, __builtin_amdgcn_raw_buffer_load_b64(rda, a + lane8, 0, 0));
             }
-            // batches of NBF column pairs, the four k slots of a batch requested together (4 NBF lines in flight: every request round trip
-            // that is not hidden behind the next item's scan costs the whole wave ~1 us); per accumulator the k slots are applied in
-            // ascending order, kk 0-3 before kk 4-7
-            constexpr int NBF = PAIRS <= 8 ? PAIRS : 4;
-            uint32_t pmk[4];
+            // the k slots one after the other, per slot batches of NB column pairs.  (Measured on the FEM-like product, T_7: this order 1317 us;
+            // batches of four pairs with the four k slots of a batch requested together 1357 us; 8-pair windows with every line of an item
+            // in flight 1424 us -- the request round trips are not what bounds the kernel.)
 #pragma unroll
-            for (int k4 = 0; k4 < 4; k4++) pmk[k4] = (uint32_t)__builtin_amdgcn_readfirstlane((int)pm4[k4]);
+            for (int k4 = 0; k4 < 4; k4++) {
+                const uint32_t pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pm4[k4]);
+                const uint32_t *my = S.sched[tb][k4][half_sel];
 #pragma unroll
-            for (int hb = 0; hb < PAIRS / NBF; hb++) {
-                uint32_t mk[4];
+                for (int hb = 0; hb < PAIRS / NB; hb++) {
+                    const uint32_t mb = (pm >> (NB * hb)) & ((1u << NB) - 1u);
+                    if (mb) {
+                        f32x2k_t fb[NB];
 #pragma unroll
-                for (int k4 = 0; k4 < 4; k4++) mk[k4] = (pmk[k4] >> (NBF * hb)) & ((1u << NBF) - 1u);
-                if (mk[0] | mk[1] | mk[2] | mk[3]) {
-                    f32x2k_t fb[4][NBF];
-#pragma unroll
-                    for (int k4 = 0; k4 < 4; k4++) {
-#pragma unroll
-                        for (int q = 0; q < NBF; q++) {
-                            if ((mk[k4] >> q) & 1u)
-                                fb[k4][q] = __builtin_bit_cast(f32x2k_t, __builtin_amdgcn_raw_buffer_load_b64(rdb, S.sched[tb][k4][half_sel][NBF * hb + q] + lane8, 0, 0));
+                        for (int q = 0; q < NB; q++) {
+                            if ((mb >> q) & 1u) fb[q] = __builtin_bit_cast(f32x2k_t, __builtin_amdgcn_raw_buffer_load_b64(rdb, my[NB * hb + q] + lane8, 0, 0));
                         }
-                    }
-                    if (!scanned) { scan_next(); scanned = true; }
+                        if (!scanned) { scan_next(); scanned = true; }
 #pragma unroll
-                    for (int q = 0; q < NBF; q++) {
-                        float4_t c = acc[NBF * hb + q];
-#pragma unroll
-                        for (int k4 = 0; k4 < 4; k4++) {
-                            if ((mk[k4] >> q) & 1u) {
-                                c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k4][0], fb[k4][q][0], c, 0, 0, 0);  // kk 0 .. 3
-                                c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k4][1], fb[k4][q][1], c, 0, 0, 0);  // kk 4 .. 7
+                        for (int q = 0; q < NB; q++) {
+                            if ((mb >> q) & 1u) {
+                                float4_t c = acc[NB * hb + q];
+                                c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k4][0], fb[q][0], c, 0, 0, 0);  // kk 0 .. 3
+                                c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k4][1], fb[q][1], c, 0, 0, 0);  // kk 4 .. 7
+                                acc[NB * hb + q] = c;
                             }
                         }
-                        acc[NBF * hb + q] = c;
                     }
                 }
             }
@@ -566,8 +558,7 @@ void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipS
     // of the 803 us kernel on the ceiling case: the next item's scan run twice +208 us, the B lines requested out of range -99 us; C tiles
     // leaving as 256-byte runs through LDS instead of per-value stores: 803 -> 776 us.
     const dim3 grid((strips + 3) / 4);
-    if (f32 && getenv("BMSP_STRIP_F32_W16")) hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3, true>), grid, dim3(kThreads), 0, st, g);  // experiment switch
-    else if (f32) hipLaunchKernelGGL((block_mac_strip_kernel<8, 8, 3, true>), grid, dim3(kThreads), 0, st, g);
+    if (f32) hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3, true>), grid, dim3(kThreads), 0, st, g);
     else if (getenv("BMSP_STRIP_WIDE")) hipLaunchKernelGGL((block_mac_strip_kernel<16, 16, 2>), grid, dim3(kThreads), 0, st, g);  // experiment switch
     else hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3>), grid, dim3(kThreads), 0, st, g);
     BMSP_CHECK_LAUNCH();

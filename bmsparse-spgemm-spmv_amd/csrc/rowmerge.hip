@@ -62,7 +62,7 @@ struct WalkArgs {
 // used).  step(live, a, t, j, abm, bbm) is called by the whole wave once per step -- live: this lane holds a candidate (A tile a, B
 // tile t of block column j, their bitmaps) -- and returns false (wave-uniformly) to stop the walk.  LPT = 64: one A tile at a time, i.e.
 // the candidates arrive in ascending A tile.
-template <int LPT = 16, typename Step>
+template <int LPT = 16, int DEPTH = 4, typename Step>
 __device__ __forceinline__ bool walk_row(const WalkArgs &g, ChunkLds &L, uint32_t a0, uint32_t a1, int lane, Step step)
 {
     constexpr uint32_t GROUPS = 64 / LPT;
@@ -109,14 +109,38 @@ __device__ __forceinline__ bool walk_row(const WalkArgs &g, ChunkLds &L, uint32_
             }
             return n;
         };
-        // four steps in flight: a step's words have three steps' time to arrive (one step ahead measured 892 us for the cage-like fill
-        // pass at 12 waves per CU)
-        Cur q0 = enter(), q1 = after(q0), q2 = after(q1), q3 = after(q2);
-        while (q0.valid) {
-            if (__any(q0.t < q0.end)) {
-                if (!step(q0.t < q0.end, base + q0.u, q0.t, q0.j, q0.abm, q0.bbm)) return false;
+        // DEPTH steps in flight: a step's words have DEPTH - 1 steps' time to arrive.  DEPTH 1: the next step of the SAME group only (the
+        // first step of a group waits for its words) -- fewest instructions per step, and the fastest form where four A tiles share a
+        // step (FEM-like strip-mode pass 298 us; two or four steps in flight across groups 352 / 363 us)
+        static_assert(DEPTH == 1 || DEPTH == 2 || DEPTH == 4, "one, two or four steps in flight");
+        if constexpr (DEPTH == 1) {
+            for (g4 = 0; g4 < na; g4 += GROUPS) {
+                Cur c = enter();
+                while (__any(c.t < c.end)) {
+                    const uint32_t tn = c.t + (uint32_t)LPT;
+                    uint32_t jn = 0;
+                    uint64_t bn = 0;
+                    if (tn < c.end) { jn = key_col(g.b_keys[tn]); bn = g.b_bmps[tn]; }
+                    if (!step(c.t < c.end, base + c.u, c.t, c.j, c.abm, c.bbm)) return false;
+                    c.t = tn; c.j = jn; c.bbm = bn;
+                }
             }
-            q0 = q1; q1 = q2; q2 = q3; q3 = after(q3);
+        } else if constexpr (DEPTH == 4) {
+            Cur q0 = enter(), q1 = after(q0), q2 = after(q1), q3 = after(q2);
+            while (q0.valid) {
+                if (__any(q0.t < q0.end)) {
+                    if (!step(q0.t < q0.end, base + q0.u, q0.t, q0.j, q0.abm, q0.bbm)) return false;
+                }
+                q0 = q1; q1 = q2; q2 = q3; q3 = after(q3);
+            }
+        } else {
+            Cur q0 = enter(), q1 = after(q0);
+            while (q0.valid) {
+                if (__any(q0.t < q0.end)) {
+                    if (!step(q0.t < q0.end, base + q0.u, q0.t, q0.j, q0.abm, q0.bbm)) return false;
+                }
+                q0 = q1; q1 = after(q1);
+            }
         }
     }
     return true;
@@ -148,6 +172,7 @@ __device__ __forceinline__ uint32_t xcd_order(uint32_t b, uint32_t G)
     return (x < rm ? x * (q + 1) : rm * (q + 1) + (x - rm) * q) + b / 8;
 }
 
+template <int DEPTH>
 __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArgs g)
 {
     __shared__ RowLds lds_all[4];
@@ -165,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
     uint32_t n = 0;       // distinct columns so far (wave-uniform)
     uint32_t surv = 0;    // this lane's surviving pairs
     const WalkArgs wa{g.a_keys, g.a_bmps, g.b_keys, g.b_bmps, g.b_rowptr, g.b_block_rows};
-    const bool done = walk_row(wa, S.ch, a0, a1, lane, [&](bool live, uint32_t, uint32_t, uint32_t j, uint64_t abm, uint64_t bbm) {
+    const bool done = walk_row<16, DEPTH>(wa, S.ch, a0, a1, lane, [&](bool live, uint32_t, uint32_t, uint32_t j, uint64_t abm, uint64_t bbm) {
         if (n > g.row_cap) return false;
         const bool keep = live && !tile_product_empty(abm, bbm);  // multiplication_checker (:742-757)
         surv += keep ? 1u : 0u;
@@ -264,6 +289,7 @@ struct alignas(16) BuildLds {
 };  // 13 KB per wave
 
 
+template <int DEPTH>
 __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g)
 {
     __shared__ BuildLds lds_all[4];
@@ -285,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g
     bool done = a1 - a0 <= 65535u;
     // (one A tile at a time: the columns of one block-row of B are distinct, so the count a pair finds at its C tile is the number of that
     // tile's tasks from smaller A tiles -- its place inside the tile, in V15's summation order (:269-273))
-    if (done) done = walk_row<64>(g.w, S.ch, a0, a1, lane, [&](bool live, uint32_t a, uint32_t t, uint32_t j, uint64_t abm, uint64_t bbm) {
+    if (done) done = walk_row<64, DEPTH>(g.w, S.ch, a0, a1, lane, [&](bool live, uint32_t a, uint32_t t, uint32_t j, uint64_t abm, uint64_t bbm) {
         if (n > kTlCap || ns + 64u > 65535u) return false;  // (task offsets inside a block-row are kept in 16 bits)
         const bool keep = live && !tile_product_empty(abm, bbm);  // multiplication_checker (:742-757)
         const uint64_t bal = __ballot(keep);
@@ -501,7 +527,7 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     g.block_rows = (uint32_t)rows; g.b_block_rows = (uint32_t)B->num_block_rows(); g.row_cap = row_cap;
     g.tmp_off = tmp_off.p; g.t_cols = t_cols.p; g.t_bmps = t_bmps.p; g.cnt = cnt.p;
     g.surv = surv_row.p; g.overflow = (uint32_t *)(acc.p + 2);
-    hipLaunchKernelGGL(rowmerge_symbolic_kernel, dim3((uint32_t)((rows + 3) / 4)), dim3(kThreads), 0, st, g);
+    hipLaunchKernelGGL(rowmerge_symbolic_kernel<1>, dim3((uint32_t)((rows + 3) / 4)), dim3(kThreads), 0, st, g);
     BMSP_CHECK_LAUNCH();
     uint32_t *c_rowptr = (uint32_t *)pool_alloc(sizeof(uint32_t) * (size_t)(rows + 1));
     HostScalar<uint32_t> c_size_h;
@@ -576,7 +602,8 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     g.s_surv = s_surv.p; g.s_prod = s_prod.p; g.s_ord = s_ord.p; g.s_tasks = s_tasks.p; g.s_cols = s_cols.p; g.s_begin = s_begin.p;
     g.s_bmps = (unsigned long long *)s_bmps.p;
     const dim3 grid((uint32_t)((rows + 3) / 4));
-    hipLaunchKernelGGL(rowmerge_build_kernel, grid, dim3(kThreads), 0, st, g);
+    if (getenv("BMSP_RM_DEPTH1")) hipLaunchKernelGGL(rowmerge_build_kernel<1>, grid, dim3(kThreads), 0, st, g);  // experiment switch
+    else hipLaunchKernelGGL(rowmerge_build_kernel<2>, grid, dim3(kThreads), 0, st, g);
     BMSP_CHECK_LAUNCH();
     uint32_t *c_rowptr = (uint32_t *)pool_alloc(sizeof(uint32_t) * (size_t)(rows + 1));
     HostScalar<uint32_t> c_size_h, n_tasks_h;
