@@ -482,7 +482,8 @@ __global__ __launch_bounds__(kThreads) void segsort_tasks_wave_kernel(uint64_t *
 // segment count nor the class counts have to travel to the host: the grid is sized by A's block-rows, surplus waves leave.
 template <typename W>
 __global__ __launch_bounds__(kThreads) void segsort_tasks_direct_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, const int *__restrict__ segs,
-                                                                        const uint32_t *__restrict__ nseg_dev, uint64_t n, uint64_t col_mask)
+                                                                        const uint32_t *__restrict__ nseg_dev, uint64_t n, uint64_t col_mask,
+                                                                        uint32_t *__restrict__ violation)
 {
     const uint32_t s = blockIdx.x * 4 + (uint32_t)wave_id();
     const uint32_t nseg = *nseg_dev;
@@ -497,7 +498,15 @@ __global__ __launch_bounds__(kThreads) void segsort_tasks_direct_kernel(uint64_t
     else if (len <= 512) sort_task_segment_regs<W, 8, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
     else if (len <= 1024) sort_task_segment_regs<W, 16, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
     else if (len <= 2048) sort_task_segment_regs<W, 32, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
-    else if constexpr (sizeof(W) == 4) sort_task_segment_regs<W, 64, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    else {
+        if constexpr (sizeof(W) == 4) {
+            if (len <= 4096) {
+                sort_task_segment_regs<W, 64, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+                return;
+            }
+        }
+        if (lane == 0) *violation = 1u;  // a segment beyond the wave's capacity: the caller's bound was wrong -- never left unsorted in silence
+    }
 }
 
 template <typename W>
@@ -697,6 +706,27 @@ bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *se
     return true;
 }
 
+// The read-back-free path trusts a bound on the longest segment that the caller derives from the operands.  Should that bound ever be
+// wrong, the kernel raises this word (pinned host memory, one per process) instead of leaving a segment unsorted; the SpGEMM looks at it
+// after its final synchronise (segsort_check_violation) and fails the call.
+static uint32_t *sort_violation_slot()
+{
+    static uint32_t *slot = [] {
+        uint32_t *p = static_cast<uint32_t *>(host_slot_acquire());
+        *(volatile uint32_t *)p = 0u;
+        return p;
+    }();
+    return slot;
+}
+void segsort_check_violation()
+{
+    volatile uint32_t *p = sort_violation_slot();
+    if (*p) {
+        *p = 0u;
+        fail(BMSP_ERR_LIMIT, "segmented sort: a task segment exceeded the capacity its bound promised (internal bound violated; result discarded)");
+    }
+}
+
 bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st, uint64_t max_seg_bound,
                              uint64_t seg_count_bound)
 {
@@ -717,10 +747,10 @@ bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals,
         const uint64_t waves = std::min<uint64_t>(seg_count_bound, n);
         if (narrow)
             hipLaunchKernelGGL((segsort_tasks_direct_kernel<uint32_t>), dim3((unsigned)((waves + 3) / 4)), dim3(kThreads), 0, st, keys.cur, perm.p, segs.p,
-                               nseg_dev.p, n, col_mask);
+                               nseg_dev.p, n, col_mask, sort_violation_slot());
         else
             hipLaunchKernelGGL((segsort_tasks_direct_kernel<uint64_t>), dim3((unsigned)((waves + 3) / 4)), dim3(kThreads), 0, st, keys.cur, perm.p, segs.p,
-                               nseg_dev.p, n, col_mask);
+                               nseg_dev.p, n, col_mask, sort_violation_slot());
         BMSP_CHECK_LAUNCH();
         device_for_each(GatherVals<uint64_t>{vals.cur, perm.p, vals.alt}, n, st);
         vals.flip();

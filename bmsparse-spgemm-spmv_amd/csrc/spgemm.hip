@@ -973,6 +973,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     };
     auto finish = [&]() {
         BMSP_HIP(hipStreamSynchronize(st));  // reference: cudaDeviceSynchronize (:1158)
+        segsort_check_violation();
         S->t_us[0] = tm.collect(S->t_us);
         S->t_us[5] += S->t_us[8];  // the reference's T_5 includes its "Segmented sort" sub-timer (:1009-1024)
         if (verbose) {
