@@ -56,6 +56,7 @@ struct StripArgs {
     const uint32_t *c_rowptr;
     float *c_vals;
     uint32_t block_rows;  // of A and C
+    unsigned long long *prof;  // PROF builds: [0] set-up, [1] scans, [2] requests + B lines + MFMAs, [3] window stores, [4] whole wave (timer ticks, summed over waves), [5] waves
 };
 
 typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte store at 4-byte alignment
@@ -150,9 +151,12 @@ __device__ __forceinline__ uint32_t row_or_u32(uint32_t v)
 // requests together, OCC = waves per SIMD the register allocation is held to
 // F32: fp32 operands on v_mfma_f32_16x16x4_f32 -- the k slots of an item are walked one after the other (two instructions per tile: kk 0-3,
 // kk 4-7), which is V15's summation order exactly (ascending fmaf chain, established on the hardware by mfma_f32_selftest)
-template <int PAIRS, int NB, int OCC, bool F32 = false>
+// PROF (BMSP_STRIP_PROF=1, timing builds): where a wave's time goes, by s_memtime stamps at the phase boundaries
+template <int PAIRS, int NB, int OCC, bool F32 = false, bool PROF = false>
 __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArgs g)
 {
+    const uint64_t t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    uint64_t t_scan = 0, t_store = 0, t_wait = 0;
     __shared__ StripLds lds_all[4];
     const int w = wave_id(), lane = lane_id();
     StripLds &S = lds_all[w];
@@ -285,8 +289,10 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
                 hits += (uint32_t)__popcll((__ballot(inwin) >> (16 * ks)) & 0xffffull);
             }
             pre.cur += hits;
-            if (!__any(hits == 32u)) break;
-            // every tile fetched for some k slot lay inside the window: there may be more of them
+            // every tile fetched for some k slot lay inside the window: there may be more of them -- unless the last one already stands in
+            // the window's last column (columns ascend).  (Without that test every scan of a dense band -- 32 tiles of B's block-row per
+            // window -- paid a second, exposed round trip: the timing build's 207 K of 672 K ticks per wave on the ceiling case.)
+            if (!__any(hits == 32u && q16 == 15 && pre.col[1] < jhi && pre.cur < pre.end)) break;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const uint32_t t = pre.cur + (uint32_t)(16 * h + q16);
@@ -315,13 +321,16 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
 #pragma unroll
     for (int p = 0; p < PAIRS; p++) acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
     uint32_t tb = 0;
+    const uint64_t t_loop = PROF ? __builtin_readcyclecounter() : 0ull;
     while (cur.on) {
         const Item nn = next_item(nxt);
         // while the item's B lines travel: the scan of the next item into the other table, and the key request of the one after
         auto scan_next = [&]() {
+            const uint64_t ts = PROF ? __builtin_readcyclecounter() : 0ull;
             scan(nxt, tb ^ 1u, pre);
             __builtin_amdgcn_wave_barrier();
             pre = request(nn);
+            if (PROF) t_scan += __builtin_readcyclecounter() - ts;
         };
         typedef uint32_t u32x4k_t __attribute__((ext_vector_type(4)));
         const u32x4k_t pm4 = *(const u32x4k_t *)S.pmask[tb];
@@ -381,6 +390,11 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
                             if ((mb >> q) & 1u) fb[q] = __builtin_bit_cast(f32x2k_t, __builtin_amdgcn_raw_buffer_load_b64(rdb, my[NB * hb + q] + lane8, 0, 0));
                         }
                         if (!scanned) { scan_next(); scanned = true; }
+                        if (PROF) {  // (timing build: the wait for the batch's lines apart from its MFMAs)
+                            const uint64_t tq = __builtin_readcyclecounter();
+                            __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0)
+                            t_wait += __builtin_readcyclecounter() - tq;
+                        }
 #pragma unroll
                         for (int q = 0; q < NB; q++) {
                             if ((mb >> q) & 1u) {
@@ -401,6 +415,7 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
         if (lane < 4) S.pmask[tb][lane] = 0u;
         __builtin_amdgcn_wave_barrier();
         if (cur.gi + 1 == nG) {
+            const uint64_t tw = PROF ? __builtin_readcyclecounter() : 0ull;
             // ---- the window is complete: lane holds D[4 * (lane >> 4) + i][lane & 15] = rows d_r0 + i of C(row d_row, column 2p + half_sel) ----
             const uint32_t s0 = SLOTS * cur.wi, ns = min(SLOTS, nJ - s0);
             const uint32_t crow0 = d_row ? c0e : c0b;
@@ -414,13 +429,19 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
 #pragma unroll
             for (int p0 = 0; p0 < PAIRS; p0 += PG) {
                 if (2u * (uint32_t)p0 < ns) {
-                    uint64_t ocb[PG], oco[PG];
+                    // the C words of the group's tiles in BOTH lane layouts, requested together (per-pair requests in the per-value path below
+                    // were a dependent round trip per pair: 43 % of the FEM-like fp16 kernel by the timing build)
+                    uint64_t ocb[PG], oco[PG], acb[PG], aco[PG];
 #pragma unroll
                     for (int q = 0; q < PG; q++) {
                         const uint32_t sl = 2u * (uint32_t)(p0 + q) + (uint32_t)o_col;
                         const uint32_t crel = sl < ns ? (uint32_t)S.jc[s0 + sl][o_row] : 0xffffu;
                         ocb[q] = ~0ull; oco[q] = ~0ull;  // no tile: nothing to store, and no reason to leave the fast path
                         if (crel != 0xffffu) { ocb[q] = g.c_bmps[orow0 + crel]; oco[q] = g.c_offs[orow0 + crel]; }
+                        const uint32_t sla = 2u * (uint32_t)(p0 + q) + (uint32_t)half_sel;
+                        const uint32_t crela = sla < ns ? (uint32_t)S.jc[s0 + sla][d_row] : 0xffffu;
+                        acb[q] = 0ull; aco[q] = 0ull;    // no tile: no bit, no store
+                        if (crela != 0xffffu) { acb[q] = g.c_bmps[crow0 + crela]; aco[q] = g.c_offs[crow0 + crela]; }
                     }
 #pragma unroll
                     for (int q = 0; q < PG; q++) {
@@ -434,16 +455,11 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
                             if (oco[q] != ~0ull) *(float4_u *)(g.c_vals + oco[q] + 4u * (uint32_t)o_q) = v;
                             __builtin_amdgcn_wave_barrier();
                         } else {
-                            const uint32_t sl = 2u * (uint32_t)p + (uint32_t)half_sel;
-                            const uint32_t crel = sl < ns ? (uint32_t)S.jc[s0 + sl][d_row] : 0xffffu;
-                            if (crel != 0xffffu) {
-                                const uint32_t c = crow0 + crel;
-                                const uint64_t cb = g.c_bmps[c], co = g.c_offs[c];
+                            const uint64_t cb = acb[q], co = aco[q];
 #pragma unroll
-                                for (int i = 0; i < 4; i++) {
-                                    const uint32_t pos = (d_r0 + (uint32_t)i) * 8u + (uint32_t)line;
-                                    if ((cb >> (63u - pos)) & 1ull) g.c_vals[co + (uint64_t)__popcll(cb >> 1 >> (63u - pos))] = acc[p][i];
-                                }
+                            for (int i = 0; i < 4; i++) {
+                                const uint32_t pos = (d_r0 + (uint32_t)i) * 8u + (uint32_t)line;
+                                if ((cb >> (63u - pos)) & 1ull) g.c_vals[co + (uint64_t)__popcll(cb >> 1 >> (63u - pos))] = acc[p][i];
                             }
                         }
                     }
@@ -451,9 +467,20 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
 #pragma unroll
                 for (int q = 0; q < PG; q++) acc[p0 + q] = float4_t{0.f, 0.f, 0.f, 0.f};
             }
+            if (PROF) t_store += __builtin_readcyclecounter() - tw;
         }
         cur = nxt; nxt = nn;
         tb ^= 1u;
+    }
+    if (PROF && lane == 0) {
+        const uint64_t t_end = __builtin_readcyclecounter();
+        atomicAdd(g.prof + 0, (unsigned long long)(t_loop - t_begin));
+        atomicAdd(g.prof + 1, (unsigned long long)t_scan);
+        atomicAdd(g.prof + 2, (unsigned long long)(t_end - t_loop - t_scan - t_store));
+        atomicAdd(g.prof + 3, (unsigned long long)t_store);
+        atomicAdd(g.prof + 4, (unsigned long long)(t_end - t_begin));
+        atomicAdd(g.prof + 5, 1ull);
+        atomicAdd(g.prof + 6, (unsigned long long)t_wait);
     }
 }
 
@@ -558,6 +585,21 @@ void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipS
     // of the 803 us kernel on the ceiling case: the next item's scan run twice +208 us, the B lines requested out of range -99 us; C tiles
     // leaving as 256-byte runs through LDS instead of per-value stores: 803 -> 776 us.
     const dim3 grid((strips + 3) / 4);
+    if (getenv("BMSP_STRIP_PROF")) {  // timing build: per-phase timer ticks, printed per launch
+        DevBuf<unsigned long long> prof(8);
+        BMSP_HIP(hipMemsetAsync(prof.p, 0, 64, st));
+        g.prof = prof.p;
+        if (f32) hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3, true, true>), grid, dim3(kThreads), 0, st, g);
+        else hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3, false, true>), grid, dim3(kThreads), 0, st, g);
+        BMSP_CHECK_LAUNCH();
+        unsigned long long h[8];
+        BMSP_HIP(hipMemcpyAsync(h, prof.p, 64, hipMemcpyDeviceToHost, st));
+        BMSP_HIP(hipStreamSynchronize(st));
+        const double w = (double)(h[5] ? h[5] : 1);
+        fprintf(stderr, "strip prof (ticks per wave, %llu waves): set-up %.0f  scans %.0f  requests+lines+mfma %.0f (of which waiting for lines, fp32 build: %.0f)  stores %.0f  whole %.0f\n", h[5], h[0] / w,
+                h[1] / w, h[2] / w, h[6] / w, h[3] / w, h[4] / w);
+        return;
+    }
     if (f32) hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3, true>), grid, dim3(kThreads), 0, st, g);
     else if (getenv("BMSP_STRIP_WIDE")) hipLaunchKernelGGL((block_mac_strip_kernel<16, 16, 2>), grid, dim3(kThreads), 0, st, g);  // experiment switch
     else hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3>), grid, dim3(kThreads), 0, st, g);
