@@ -760,7 +760,7 @@ def test_spgemm_rowmerge_path(oracle, bmsp, monkeypatch, case, dtype):
     assert st2["sort_path"] == 0
 
 
-@pytest.mark.parametrize("case", ["banded64", "fem", "rect_ragged", "filtered_run", "empty_strips", "cage_wide"])
+@pytest.mark.parametrize("case", ["banded64", "banded_wide", "fem", "rect_ragged", "filtered_run", "empty_strips", "cage_wide"])
 @pytest.mark.parametrize("dtype,tc", [(1, 4), (0, 5), (1, 5), (2, 5), (1, 1)])
 def test_spgemm_rowmerge_task_list(oracle, bmsp, monkeypatch, case, dtype, tc):
     """Task-list mode of the row-merge path (BMSP_SPGEMM_ROWMERGE=2 skips strip mode): a count pass and a fill pass form C's keys,
