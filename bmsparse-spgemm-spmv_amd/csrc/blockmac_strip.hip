@@ -493,12 +493,17 @@ struct NonFiniteF16 {
         if ((v[i] & 0x7c00u) == 0x7c00u) *flag = 1u;
     }
 };
-struct NonFiniteF32 {
+// fp32: the largest biased exponent, and 255 - the smallest biased exponent among the non-zero values, in one reduction each
+struct ExpMaxF32 {
     const uint32_t *v;
-    uint32_t *flag;
-    __device__ void operator()(uint64_t i) const
+    __device__ uint64_t operator()(uint64_t i) const { return (uint64_t)((v[i] >> 23) & 0xffu); }
+};
+struct ExpMinF32 {
+    const uint32_t *v;
+    __device__ uint64_t operator()(uint64_t i) const
     {
-        if ((v[i] & 0x7f800000u) == 0x7f800000u) *flag = 1u;
+        const uint32_t w = v[i] & 0x7fffffffu;
+        return w ? (uint64_t)(255u - (w >> 23)) : 0ull;  // explicit zeros do not count: their products are exact zeros
     }
 };
 
@@ -508,13 +513,27 @@ void ensure_finite_flag(bmsp_matrix_s *m, hipStream_t st)
 {
     if (m->values_finite >= 0) return;
     if (m->dtype == BMSP_F64 || m->nnz == 0) { m->values_finite = 1; return; }
-    DevBuf<uint32_t> flag(1);
-    BMSP_HIP(hipMemsetAsync(flag.p, 0, 4, st));
     const uint64_t base = m->view_values_end ? read_back(m->offsets, st) : 0;
     const uint64_t n = (uint64_t)m->values_extent() - base;
-    if (m->dtype == BMSP_F16) device_for_each(NonFiniteF16{(const uint16_t *)m->values + base, flag.p}, n, st);
-    else device_for_each(NonFiniteF32{(const uint32_t *)m->values + base, flag.p}, n, st);
-    m->values_finite = read_back(flag.p, st) ? 0 : 1;
+    if (m->dtype == BMSP_F16) {
+        DevBuf<uint32_t> flag(1);
+        BMSP_HIP(hipMemsetAsync(flag.p, 0, 4, st));
+        device_for_each(NonFiniteF16{(const uint16_t *)m->values + base, flag.p}, n, st);
+        m->values_finite = read_back(flag.p, st) ? 0 : 1;
+        return;
+    }
+    // fp32: the exponent range as well -- the fp32 MFMA reproduces the fmaf chain bit for bit only while no product underflows
+    // (measured: products around 2^-149 round differently in the matrix pipe) and none overflows
+    DevBuf<unsigned long long> mx(2);
+    BMSP_HIP(hipMemsetAsync(mx.p, 0, 16, st));
+    device_max_sum(ExpMaxF32{(const uint32_t *)m->values + base}, n, mx.p, (unsigned long long *)nullptr, st);
+    device_max_sum(ExpMinF32{(const uint32_t *)m->values + base}, n, mx.p + 1, (unsigned long long *)nullptr, st);
+    unsigned long long h[2];
+    BMSP_HIP(hipMemcpyAsync(h, mx.p, 16, hipMemcpyDeviceToHost, st));
+    BMSP_HIP(hipStreamSynchronize(st));
+    m->f32_exp_max = (int)h[0];
+    m->f32_exp_min = h[1] ? 255 - (int)h[1] : 255;  // no non-zero value: nothing can underflow
+    m->values_finite = h[0] == 255ull ? 0 : 1;
 }
 
 // what the strip kernel needs of the operands alone: fp16 tiles the K = 32 MFMA path addresses, a strip's merged A tiles within the k
@@ -526,6 +545,11 @@ bool mac_strip_operands_ok(bmsp_matrix_s *A, bmsp_matrix_s *B, hipStream_t st)
     } else if (A->dtype == BMSP_F32) {
         // 256-byte tiles behind 32-bit byte offsets; the instruction's summation order is checked on the device once per process
         if (B->dtype != BMSP_F32 || A->block_num >= (1ll << 24) || B->block_num >= (1ll << 24) || !mac_f32_mfma_usable(st)) return false;
+        // every product a normal number (|a| |b| >= 2^(ea + eb - 254) >= 2^-126) and every sum far from overflow: outside that range the
+        // matrix pipe's rounding is not the fmaf chain's, and V15's vector-ALU kernel (task-list mode or the pipeline) takes the product
+        ensure_finite_flag(A, st);
+        ensure_finite_flag(B, st);
+        if (A->f32_exp_min + B->f32_exp_min < 128 || A->f32_exp_max + B->f32_exp_max > 254 + 100) return false;
     } else {
         return false;
     }

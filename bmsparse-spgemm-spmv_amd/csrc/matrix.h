@@ -43,7 +43,8 @@ struct bmsp_matrix_s {
     const void *rm_partner_keys = nullptr;
     int64_t rm_partner_blocks = 0;
     int rm_partner_mode = 0;
-    int values_finite = -1;       // fp16 operands of the strip block-MAC: 1 = no inf / NaN stored (-1 = not looked yet)
+    int values_finite = -1;
+    int f32_exp_min = 255, f32_exp_max = 0;  // fp32: biased exponent range of the non-zero stored values (with values_finite)       // fp16 operands of the strip block-MAC: 1 = no inf / NaN stored (-1 = not looked yet)
     // a row-panel view points into its parent
     int64_t view_block_begin = 0;
     // sharded SpMV (comm.hip): this rank's panel view, kept for its cached sweep plan

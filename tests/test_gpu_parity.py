@@ -778,6 +778,7 @@ def test_spgemm_rowmerge_task_list(oracle, bmsp, monkeypatch, case, dtype, tc):
         if Bc is None:
             Bc = A
         monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "2")
+        monkeypatch.setenv("BMSP_MAC_STRIP", "0")  # (dense bands would otherwise take the strip kernel from the task-list structure too)
     st = check_spgemm(oracle, bmsp, A, Bc, dtype, 0, tc, exact_expected=exact)
     assert st["sort_path"] == 2 and st["mac_variant"] != 3, st
     a = bmsp.BmSpMatrix.from_coo(*A, dtype=dtype)
@@ -792,6 +793,24 @@ def test_spgemm_rowmerge_task_list(oracle, bmsp, monkeypatch, case, dtype, tc):
     for x, y, z in zip(old.host_arrays(), new.host_arrays(), new2.host_arrays()):
         np.testing.assert_array_equal(x, y)
         np.testing.assert_array_equal(x, z)
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-20, 3e-23, 1e19])
+def test_spgemm_fp32_exponent_range_keeps_v15(oracle, bmsp, scale):
+    """fp32 products whose partial products leave the normal range: v_mfma_f32_16x16x4_f32 rounds products around 2^-149 differently
+    from fmaf (measured: 3e-23-scaled FEM values), so the fp32 strip kernel is only taken while |a| |b| >= 2^-126 for every pair of stored
+    values (and sums stay far from overflow); otherwise the vector-ALU kernel runs from the row-merge task list.  Either way C is the
+    oracle's bit for bit -- denormal results included."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.fem_like(10, "27pt")
+    vv = (v * scale).astype(np.float32).astype(np.float64)
+    A = (n, n, r, c, vv)
+    st = check_spgemm(oracle, bmsp, A, A, 0, 0, 5, exact_expected=True)
+    assert st["sort_path"] == 2, st
+    if scale in (3e-23, 1e19):
+        assert st["mac_variant"] != 3, st   # products underflow / may overflow: not the matrix pipe
+    elif scale == 1.0:
+        assert st["mac_variant"] == 3, st
 
 
 @pytest.mark.parametrize("case", ["rmat", "banded", "filtered", "rect"])
