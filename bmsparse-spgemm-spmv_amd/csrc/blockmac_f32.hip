@@ -264,6 +264,10 @@ bool launch_mac_f32_mfma(const uint64_t *tasks, uint64_t n_tasks, const uint32_t
     if (A->dtype != BMSP_F32 || n_tasks >= (1ull << 29) || A->block_num >= (1ll << 24) || B->block_num >= (1ll << 24)) return false;
     const uint32_t cs = (uint32_t)C->block_num;
     if (!mac_f32_mfma_usable(st)) return false;
+    // (the instruction is the fmaf chain only while every product is a normal number: see mac_strip_operands_ok)
+    ensure_finite_flag(A, st);
+    ensure_finite_flag(B, st);
+    if (A->values_finite != 1 || B->values_finite != 1 || A->f32_exp_min + B->f32_exp_min < 128 || A->f32_exp_max + B->f32_exp_max > 354) return false;
     ensure_lane_tiles(A, st);
     ensure_lane_tiles(B, st);
     MacF32Args g{};
