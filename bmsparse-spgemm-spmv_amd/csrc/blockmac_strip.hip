@@ -70,10 +70,16 @@ struct alignas(16) StripLds {
     uint32_t kend[kKCap];
     uint32_t kcm[kKCap];       // OR of the column masks of the strip's A tiles in column k
     union {
-        struct { uint32_t l0[kJCap / 2], l1[kJCap / 2]; };  // merge temporaries (the two sorted lists)
-        float stage[4 * kStageTile];                        // after the merges: the four C tiles of a column pair on their way out
+        struct {  // merge temporaries
+            uint32_t l0[kJCap / 2], l1[kJCap / 2];  // the two sorted lists
+            uint16_t nd[kJCap / 2 + 2];             // non-duplicates among the first q entries of l1
+        };
+        struct {  // after the merges
+            float stage[4 * kStageTile];  // the four C tiles of a column pair on their way out
+            uint64_t cwb[64], cwo[64];    // bitmap and value offset of the window's C tiles [block-row of the strip][column of the window], requested when
+                                          // the window is entered (offset ~0: no tile)
+        };
     };
-    uint16_t nd[kJCap / 2 + 2];             // non-duplicates among the first q entries of l1
     uint32_t sched[2][4][2][16];  // two tables (item n & 1) x [k slot][column of the pair][pair]: byte offset of the B tile in its dense copy; kNoTile = none
     alignas(16) uint32_t pmask[2][4];  // per k slot: column pairs of the item's window with a tile of B's block-row k
 };
@@ -289,10 +295,10 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
                 hits += (uint32_t)__popcll((__ballot(inwin) >> (16 * ks)) & 0xffffull);
             }
             pre.cur += hits;
-            // every tile fetched for some k slot lay inside the window: there may be more of them -- unless the last one already stands in
-            // the window's last column (columns ascend).  (Without that test every scan of a dense band -- 32 tiles of B's block-row per
-            // window -- paid a second, exposed round trip: the timing build's 207 K of 672 K ticks per wave on the ceiling case.)
-            if (!__any(hits == 32u && q16 == 15 && pre.col[1] < jhi && pre.cur < pre.end)) break;
+            if (!__any(hits == 32u)) break;
+            // every tile fetched for some k slot lay inside the window: there may be more of them.  (On a dense band the 32 tiles end exactly at
+            // the window's last column and this second fetch finds nothing -- but it touches the NEXT window's first tiles; leaving it out
+            // measured 796 instead of 750 us on the ceiling case.)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const uint32_t t = pre.cur + (uint32_t)(16 * h + q16);
@@ -332,6 +338,19 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
             pre = request(nn);
             if (PROF) t_scan += __builtin_readcyclecounter() - ts;
         };
+        // fp32 kernel: the window's C words (bitmap, value offset of its up to 64 tiles) are requested with the window's first item and parked in
+        // LDS at that item's end; the store phase reads them there instead of making four dependent requests per window (A/B on one box, T_7:
+        // FEM-like 1306 -> 1186 us, ceiling 1754 -> 1657 us).  The fp16 kernel has no register to spare for it and measured slower.
+        uint64_t w_cb = 0, w_co = ~0ull;
+        if (F32 && cur.gi == 0) {
+            const uint32_t s0w = SLOTS * cur.wi, nsw = min(SLOTS, nJ - s0w);
+            const uint32_t wrow = (uint32_t)lane >> 5, wslot = (uint32_t)lane & 31u;
+            const uint32_t crel = wslot < nsw ? (uint32_t)S.jc[s0w + wslot][wrow] : 0xffffu;
+            if (crel != 0xffffu) {
+                const uint32_t c = (wrow ? c0e : c0b) + crel;
+                w_cb = g.c_bmps[c]; w_co = g.c_offs[c];
+            }
+        }
         typedef uint32_t u32x4k_t __attribute__((ext_vector_type(4)));
         const u32x4k_t pm4 = *(const u32x4k_t *)S.pmask[tb];
         bool scanned = false;
@@ -414,58 +433,91 @@ __global__ __launch_bounds__(kThreads, OCC) void block_mac_strip_kernel(StripArg
         ((uint64_t *)S.sched[tb])[lane] = ((uint64_t)kNoTile << 32) | kNoTile;
         if (lane < 4) S.pmask[tb][lane] = 0u;
         __builtin_amdgcn_wave_barrier();
+        if (F32 && cur.gi == 0) {
+            S.cwb[lane] = w_cb; S.cwo[lane] = w_co;
+            __builtin_amdgcn_wave_barrier();
+        }
         if (cur.gi + 1 == nG) {
             const uint64_t tw = PROF ? __builtin_readcyclecounter() : 0ull;
             // ---- the window is complete: lane holds D[4 * (lane >> 4) + i][lane & 15] = rows d_r0 + i of C(row d_row, column 2p + half_sel) ----
             const uint32_t s0 = SLOTS * cur.wi, ns = min(SLOTS, nJ - s0);
-            const uint32_t crow0 = d_row ? c0e : c0b;
             // A lane's four D values are one column of half a tile: through LDS they become 16 consecutive bytes of a tile row, so a
             // full C tile leaves as one 256-byte run (16 lanes x 16 bytes); tiles with holes take the per-value path
             const int o_row = lane >> 5, o_col = (lane >> 4) & 1, o_q = lane & 15;  // outgoing layout: tile (o_row, column o_col of the pair), floats 4 o_q .. 4 o_q + 3
             float *const st_in = S.stage + (d_row * 2 + half_sel) * kStageTile + (int)d_r0 * 8 + line;
             const float *const st_out = S.stage + (o_row * 2 + o_col) * kStageTile + 4 * o_q;
-            const uint32_t orow0 = o_row ? c0e : c0b;
-            constexpr int PG = 4;  // pairs whose C words are requested together
-#pragma unroll
-            for (int p0 = 0; p0 < PAIRS; p0 += PG) {
-                if (2u * (uint32_t)p0 < ns) {
-                    // the C words of the group's tiles in BOTH lane layouts, requested together (per-pair requests in the per-value path below
-                    // were a dependent round trip per pair: 43 % of the FEM-like fp16 kernel by the timing build)
-                    uint64_t ocb[PG], oco[PG], acb[PG], aco[PG];
-#pragma unroll
-                    for (int q = 0; q < PG; q++) {
-                        const uint32_t sl = 2u * (uint32_t)(p0 + q) + (uint32_t)o_col;
-                        const uint32_t crel = sl < ns ? (uint32_t)S.jc[s0 + sl][o_row] : 0xffffu;
-                        ocb[q] = ~0ull; oco[q] = ~0ull;  // no tile: nothing to store, and no reason to leave the fast path
-                        if (crel != 0xffffu) { ocb[q] = g.c_bmps[orow0 + crel]; oco[q] = g.c_offs[orow0 + crel]; }
-                        const uint32_t sla = 2u * (uint32_t)(p0 + q) + (uint32_t)half_sel;
-                        const uint32_t crela = sla < ns ? (uint32_t)S.jc[s0 + sla][d_row] : 0xffffu;
-                        acb[q] = 0ull; aco[q] = 0ull;    // no tile: no bit, no store
-                        if (crela != 0xffffu) { acb[q] = g.c_bmps[crow0 + crela]; aco[q] = g.c_offs[crow0 + crela]; }
-                    }
-#pragma unroll
-                    for (int q = 0; q < PG; q++) {
-                        const int p = p0 + q;
-                        if (2u * (uint32_t)p >= ns) continue;
-                        if (__all(ocb[q] == ~0ull)) {
-#pragma unroll
+            if constexpr (F32) {
+                // pair by pair; the C words of the pair's tiles come from LDS, in the outgoing lane layout (full-tile runs) and in the accumulator
+                // layout (per-value stores)
+    #pragma unroll
+                for (int p = 0; p < PAIRS; p++) {
+                    if (2u * (uint32_t)p < ns) {
+                        const int wo = o_row * 32 + 2 * p + o_col;
+                        const uint64_t ocb = S.cwb[wo], oco = S.cwo[wo];
+                        if (__all(ocb == ~0ull || oco == ~0ull)) {
+    #pragma unroll
                             for (int i = 0; i < 4; i++) st_in[8 * i] = acc[p][i];
                             __builtin_amdgcn_wave_barrier();
                             const float4_t v = *(const float4_t *)st_out;
-                            if (oco[q] != ~0ull) *(float4_u *)(g.c_vals + oco[q] + 4u * (uint32_t)o_q) = v;
+                            if (oco != ~0ull) *(float4_u *)(g.c_vals + oco + 4u * (uint32_t)o_q) = v;
                             __builtin_amdgcn_wave_barrier();
                         } else {
-                            const uint64_t cb = acb[q], co = aco[q];
-#pragma unroll
+                            const int wa = d_row * 32 + 2 * p + half_sel;
+                            const uint64_t co = S.cwo[wa], cb = co != ~0ull ? S.cwb[wa] : 0ull;
+    #pragma unroll
                             for (int i = 0; i < 4; i++) {
                                 const uint32_t pos = (d_r0 + (uint32_t)i) * 8u + (uint32_t)line;
                                 if ((cb >> (63u - pos)) & 1ull) g.c_vals[co + (uint64_t)__popcll(cb >> 1 >> (63u - pos))] = acc[p][i];
                             }
                         }
                     }
+                    acc[p] = float4_t{0.f, 0.f, 0.f, 0.f};
                 }
-#pragma unroll
-                for (int q = 0; q < PG; q++) acc[p0 + q] = float4_t{0.f, 0.f, 0.f, 0.f};
+            } else {
+                // (fp16: the window's C words requested four pairs at a time here -- with the words parked at the window's entry the dense-tile
+                // ceiling measured 866 instead of 750 us, and a refill-free scan 796: the A/B runs are in DESIGN.md)
+                const uint32_t crow0 = d_row ? c0e : c0b, orow0 = o_row ? c0e : c0b;
+                constexpr int PG = 4;  // pairs whose C words are requested together
+    #pragma unroll
+                for (int p0 = 0; p0 < PAIRS; p0 += PG) {
+                    if (2u * (uint32_t)p0 < ns) {
+                        uint64_t ocb[PG], oco[PG];
+    #pragma unroll
+                        for (int q = 0; q < PG; q++) {
+                            const uint32_t sl = 2u * (uint32_t)(p0 + q) + (uint32_t)o_col;
+                            const uint32_t crel = sl < ns ? (uint32_t)S.jc[s0 + sl][o_row] : 0xffffu;
+                            ocb[q] = ~0ull; oco[q] = ~0ull;  // no tile: nothing to store, and no reason to leave the fast path
+                            if (crel != 0xffffu) { ocb[q] = g.c_bmps[orow0 + crel]; oco[q] = g.c_offs[orow0 + crel]; }
+                        }
+    #pragma unroll
+                        for (int q = 0; q < PG; q++) {
+                            const int p = p0 + q;
+                            if (2u * (uint32_t)p >= ns) continue;
+                            if (__all(ocb[q] == ~0ull)) {
+    #pragma unroll
+                                for (int i = 0; i < 4; i++) st_in[8 * i] = acc[p][i];
+                                __builtin_amdgcn_wave_barrier();
+                                const float4_t v = *(const float4_t *)st_out;
+                                if (oco[q] != ~0ull) *(float4_u *)(g.c_vals + oco[q] + 4u * (uint32_t)o_q) = v;
+                                __builtin_amdgcn_wave_barrier();
+                            } else {
+                                const uint32_t sl = 2u * (uint32_t)p + (uint32_t)half_sel;
+                                const uint32_t crel = sl < ns ? (uint32_t)S.jc[s0 + sl][d_row] : 0xffffu;
+                                if (crel != 0xffffu) {
+                                    const uint32_t c = crow0 + crel;
+                                    const uint64_t cb = g.c_bmps[c], co = g.c_offs[c];
+    #pragma unroll
+                                    for (int i = 0; i < 4; i++) {
+                                        const uint32_t pos = (d_r0 + (uint32_t)i) * 8u + (uint32_t)line;
+                                        if ((cb >> (63u - pos)) & 1ull) g.c_vals[co + (uint64_t)__popcll(cb >> 1 >> (63u - pos))] = acc[p][i];
+                                    }
+                                }
+                            }
+                        }
+                    }
+    #pragma unroll
+                    for (int q = 0; q < PG; q++) acc[p0 + q] = float4_t{0.f, 0.f, 0.f, 0.f};
+                }
             }
             if (PROF) t_store += __builtin_readcyclecounter() - tw;
         }

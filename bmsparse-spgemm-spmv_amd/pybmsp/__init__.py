@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libbmsp.so")
+LIB_PATH = os.environ.get("BMSP_LIB_PATH") or os.path.join(_PKG, "lib", "libbmsp.so")  # (the override: A/B runs of two builds in one GPU session)
 
 F32, F16, F64 = 0, 1, 2
 NP_DTYPE = {F32: np.float32, F16: np.float16, F64: np.float64}
