@@ -282,11 +282,10 @@ struct TaskListArgs {
 
 struct alignas(16) BuildLds {
     uint32_t hk[kTlHash];       // block column; kEmpty = free
-    uint32_t tc[kTlHash / 2];   // two 16-bit fields per word (slot s: word s >> 1, half s & 1): tasks of the slot's C tile
-    uint16_t rk[kTlHash];       // rank of the slot's column among the block-row's columns = C tile relative to the block-row's first
-    uint32_t list[kTlHash];     // ranking: bit words + prefix counts of a window of columns; then the tiles' task counts in rank order and their scan
-    ChunkLds ch;
-};  // 13 KB per wave
+    uint32_t tc[kTlHash / 2];   // two 16-bit fields per word (slot s: word s >> 1, half s & 1): tasks of the slot's C tile; once the column is ranked: its rank
+    uint16_t list[kTlHash];     // the tiles' task counts in rank order, then their exclusive scan; the last 32 entries: prefix counts of the ranking's bit words
+    ChunkLds ch;                // the walk's chunk of A tiles; after the walk: the ranking's bit words (8192 columns)
+};  // 9 KB per wave: four workgroups per CU (13 KB -- separate rank array, 32-bit list, its own bit words -- held three)
 
 
 template <int DEPTH>
@@ -336,9 +335,10 @@ __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g
     // ---- rank of every column among the block-row's columns (= its C tile).  Counting sort by bitmap: the columns of a window of kWin
     //      block columns set their bit, the words' popcounts are scanned, rank = bits below.  (Counting the smaller columns per column,
     //      n^2 / 4 16-byte LDS reads per block-row, measured 390 us on the cage-like product; this form 55 us.) ----
-    constexpr uint32_t kWin = 24576, kWinWords = kWin / 64;  // 3 KB of bit words + 768 B of prefix counts inside `list`
-    uint64_t *const bw = (uint64_t *)S.list;
-    uint16_t *const bp = (uint16_t *)(S.list + 2 * kWinWords);
+    constexpr uint32_t kWin = 8192, kWinWords = kWin / 64;  // 1 KB of bit words in the chunk's place, one prefix count per four words
+    static_assert(sizeof(ChunkLds) == kWinWords * 8, "the bit words take the walk's chunk");
+    uint64_t *const bw = (uint64_t *)&S.ch;
+    uint16_t *const bp = S.list + (kTlHash - kWinWords / 4);  // (ranks stay below kTlCap + 64 = 960 <= 992)
     uint32_t jmin = kEmpty, jmax = 0;
     for (uint32_t r = 0; r < (uint32_t)kTlHash; r += 64) {
         const uint32_t key = S.hk[r + (uint32_t)lane];
@@ -358,41 +358,43 @@ __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g
             if (key != kEmpty && key - lo < kWin) atomicOr((unsigned long long *)&bw[(key - lo) >> 6], 1ull << ((key - lo) & 63u));
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t carry = 0;
-        for (uint32_t w0 = 0; w0 < kWinWords; w0 += 64) {
-            const uint32_t c = (uint32_t)__popcll(bw[w0 + (uint32_t)lane]);
+        {
+            uint32_t c = 0;
+            if (lane < (int)(kWinWords / 4))
+                c = (uint32_t)(__popcll(bw[4 * lane]) + __popcll(bw[4 * lane + 1]) + __popcll(bw[4 * lane + 2]) + __popcll(bw[4 * lane + 3]));
             const uint32_t inc = wave_inclusive_sum(c);
-            bp[w0 + (uint32_t)lane] = (uint16_t)(carry + inc - c);
-            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t r = 0; r < (uint32_t)kTlHash; r += 64) {
-            const uint32_t s = r + (uint32_t)lane;
-            const uint32_t key = S.hk[s];
-            if (key != kEmpty && key - lo < kWin) {
-                const uint32_t wd = (key - lo) >> 6, bit = (key - lo) & 63u;
-                const uint32_t rank = m + (uint32_t)bp[wd] + (uint32_t)__popcll(bw[wd] & ((1ull << bit) - 1ull));
-                S.rk[s] = (uint16_t)rank;
-                g.s_cols[off + rank] = key;
+            if (lane < (int)(kWinWords / 4)) bp[lane] = (uint16_t)(inc - c);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t r = 0; r < (uint32_t)kTlHash; r += 64) {
+                const uint32_t s = r + (uint32_t)lane;
+                const uint32_t key = S.hk[s];
+                if (key != kEmpty && key - lo < kWin) {
+                    const uint32_t wd = (key - lo) >> 6, bit = (key - lo) & 63u, w4 = wd & ~3u;
+                    uint32_t rank = m + (uint32_t)bp[wd >> 2] + (uint32_t)__popcll(bw[wd] & ((1ull << bit) - 1ull));
+                    if (wd > w4) rank += (uint32_t)__popcll(bw[w4]);
+                    if (wd > w4 + 1) rank += (uint32_t)__popcll(bw[w4 + 1]);
+                    if (wd > w4 + 2) rank += (uint32_t)__popcll(bw[w4 + 2]);
+                    // the tile's task count goes to its rank's place; the slot keeps the rank instead (xor: the neighbour slot shares the word)
+                    const uint32_t sh = 16u * (s & 1u), cnt_s = (S.tc[s >> 1] >> sh) & 0xffffu;
+                    S.list[rank] = (uint16_t)cnt_s;
+                    atomicXor(&S.tc[s >> 1], (cnt_s ^ rank) << sh);
+                    g.s_cols[off + rank] = key;
+                }
             }
+            m += total;
         }
-        m += carry;
         __builtin_amdgcn_wave_barrier();
         if (jmax - lo < kWin) break;
     }
-    // ---- task counts in rank order, their exclusive scan = first task of every C tile relative to the block-row's first ----
-    for (uint32_t r = 0; r < (uint32_t)kTlHash; r += 64) {
-        const uint32_t s = r + (uint32_t)lane;
-        if (S.hk[s] != kEmpty) S.list[S.rk[s]] = (S.tc[s >> 1] >> (16u * (s & 1u))) & 0xffffu;
-    }
-    __builtin_amdgcn_wave_barrier();
+    // ---- exclusive scan of the task counts in rank order = first task of every C tile relative to the block-row's first ----
     uint32_t carry = 0;
     for (uint32_t p0 = 0; p0 < m; p0 += 64) {
         const uint32_t p = p0 + (uint32_t)lane;
-        const uint32_t v = p < m ? S.list[p] : 0u;
+        const uint32_t v = p < m ? (uint32_t)S.list[p] : 0u;
         const uint32_t inc = wave_inclusive_sum(v);
         if (p < m) {
-            S.list[p] = carry + inc - v;
+            S.list[p] = (uint16_t)(carry + inc - v);
             g.s_begin[off + p] = carry + inc - v;
             g.s_bmps[off + p] = 0ull;
         }
@@ -409,8 +411,9 @@ __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g
         if (k < ns) {
             const uint64_t e = g.s_surv[off + k], pr = g.s_prod[off + k];
             const uint32_t ord = (uint32_t)g.s_ord[off + k];
-            const uint32_t rank = (uint32_t)S.rk[(uint32_t)(e >> 48)];
-            g.s_tasks[off + S.list[rank] + ord] = ((uint64_t)(a0 + (uint32_t)((e >> 32) & 0xffffu)) << 32) | (e & 0xffffffffull);
+            const uint32_t slot = (uint32_t)(e >> 48);
+            const uint32_t rank = (S.tc[slot >> 1] >> (16u * (slot & 1u))) & 0xffffu;
+            g.s_tasks[off + (uint32_t)S.list[rank] + ord] = ((uint64_t)(a0 + (uint32_t)((e >> 32) & 0xffffu)) << 32) | (e & 0xffffffffull);
             atomicOr(&g.s_bmps[off + rank], (unsigned long long)pr);
         }
     }
