@@ -34,6 +34,7 @@ struct RowMergeArgs {
     uint64_t *t_bmps;         //          and their bitmaps
     uint32_t *cnt;            // block_rows (+ 1, the scan reads one past): C tiles of row i
     uint32_t *surv;           // block_rows: candidate pairs of row i that passed the filter
+    uint32_t *nnz;            // block_rows: values of C's block-row i (bits of its bitmaps)
     uint32_t *overflow;
 };
 
@@ -172,6 +173,20 @@ __device__ __forceinline__ uint32_t xcd_order(uint32_t b, uint32_t G)
     return (x < rm ? x * (q + 1) : rm * (q + 1) + (x - rm) * q) + b / 8;
 }
 
+// value offsets of a block-row's C tiles: the block-row's first value + the bits of the bitmaps in front (T_9's popcount scan, :1113-1130,
+// split into a scan over the block-rows and this scan inside the block-row)
+__device__ __forceinline__ void row_value_offsets(const uint64_t *bmps, uint32_t n, uint64_t base, uint64_t *offsets, int lane)
+{
+    uint32_t carry = 0;
+    for (uint32_t p0 = 0; p0 < n; p0 += 64) {
+        const uint32_t p = p0 + (uint32_t)lane;
+        const uint32_t c = p < n ? (uint32_t)__popcll(bmps[p]) : 0u;
+        const uint32_t inc = wave_inclusive_sum(c);
+        if (p < n) offsets[p] = base + (uint64_t)(carry + inc - c);
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+}
+
 template <int DEPTH>
 __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArgs g)
 {
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
     const uint32_t a0 = g.a_rowptr[row], a1 = g.a_rowptr[row + 1];
     // (a block-row beyond the cap makes the whole pass void: the waves that start after it was seen leave at once)
     if (a0 == a1 || __builtin_nontemporal_load(g.overflow) != 0u) {
-        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; }
+        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; g.nnz[row] = 0u; }
         return;
     }
     for (uint32_t s = (uint32_t)lane; s < (uint32_t)kHash; s += 64) { S.hk[s] = kEmpty; S.hb[s] = 0ull; }
@@ -205,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
         return true;
     });
     if (!done || n > g.row_cap) {
-        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; atomicOr(g.overflow, 1u); }
+        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; g.nnz[row] = 0u; atomicOr(g.overflow, 1u); }
         return;
     }
     __builtin_amdgcn_wave_barrier();
@@ -229,6 +244,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
     // rank by column: n is small (a block-row of C), every lane counts the keys below its own; the reads are wave-wide broadcasts
     const uint32_t out0 = g.tmp_off[row];
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    uint32_t nz = 0;
     for (uint32_t p0 = 0; p0 < m; p0 += 64) {
         const uint32_t p = p0 + (uint32_t)lane;
         const uint32_t key = p < m ? S.hk[p] : kEmpty;
@@ -238,12 +254,15 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
             rank += (v[0] < key ? 1u : 0u) + (v[1] < key ? 1u : 0u) + (v[2] < key ? 1u : 0u) + (v[3] < key ? 1u : 0u);
         }
         if (p < m) {
+            const uint64_t bm = S.hb[p];
             g.t_cols[out0 + rank] = key;
-            g.t_bmps[out0 + rank] = S.hb[p];
+            g.t_bmps[out0 + rank] = bm;
+            nz += (uint32_t)__popcll(bm);
         }
     }
     surv = wave_sum(surv);
-    if (lane == 0) { g.cnt[row] = m; g.surv[row] = surv; }  // (per-row results: one atomic pair per wave would serialise at the memory side)
+    nz = wave_sum(nz);
+    if (lane == 0) { g.cnt[row] = m; g.surv[row] = surv; g.nnz[row] = nz; }  // (per-row results: one atomic pair per wave would serialise at the memory side)
 }
 
 // ---- row-merge WITH a task list: block-rows of C of up to kTlCap tiles, for the task-list block-MAC kernels ------------------------------
@@ -264,7 +283,7 @@ struct TaskListArgs {
     const uint32_t *a_rowptr;
     const uint64_t *first_pos;  // T_2: candidate pairs in front of every A tile
     uint32_t block_rows;
-    uint32_t *cnt, *surv, *overflow;
+    uint32_t *cnt, *surv, *nnz, *overflow;  // per block-row: C tiles, surviving pairs, values of C
     // scratch, indexed from the block-row's first candidate pair
     uint64_t *s_surv;   // surviving pairs in walk order: slot << 48 | (A tile - the row's first) << 32 | B tile
     uint64_t *s_prod;   // ... their tile products
@@ -275,7 +294,8 @@ struct TaskListArgs {
     unsigned long long *s_bmps;  //  C's bitmaps
     // copy pass
     const uint32_t *c_rowptr, *row_task0;
-    uint64_t *c_keys, *c_bmps;
+    const uint64_t *row_val0;
+    uint64_t *c_keys, *c_bmps, *c_offs;
     uint32_t *task_begin;
     uint64_t *tasks;
 };
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g
     if (row >= g.block_rows) return;
     const uint32_t a0 = g.a_rowptr[row], a1 = g.a_rowptr[row + 1];
     if (a0 == a1 || __builtin_nontemporal_load(g.overflow) != 0u) {
-        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; }
+        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; g.nnz[row] = 0u; }
         return;
     }
     const uint64_t off = g.first_pos[a0];
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g
         return true;
     });
     if (!done || n > kTlCap) {
-        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; atomicOr(g.overflow, 1u); }
+        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; g.nnz[row] = 0u; atomicOr(g.overflow, 1u); }
         return;
     }
     __builtin_amdgcn_wave_barrier();
@@ -417,7 +437,13 @@ __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g
             atomicOr(&g.s_bmps[off + rank], (unsigned long long)pr);
         }
     }
-    if (lane == 0) { g.cnt[row] = m; g.surv[row] = ns; }
+    // values of the block-row (bits of its finished bitmaps: read past the L1, which may still hold the zeroed lines)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    uint32_t nz = 0;
+    for (uint32_t p = (uint32_t)lane; p < m; p += 64)
+        nz += (uint32_t)__popcll(__hip_atomic_load(g.s_bmps + off + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    nz = wave_sum(nz);
+    if (lane == 0) { g.cnt[row] = m; g.surv[row] = ns; g.nnz[row] = nz; }
 }
 
 // stretches -> C's own arrays and the task list: one wave per block-row
@@ -436,6 +462,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_copy_kernel(TaskListArgs g)
         g.task_begin[c0 + r] = t0 + g.s_begin[off + r];
     }
     for (uint32_t k = (uint32_t)lane; k < ns; k += 64) g.tasks[t0 + k] = g.s_tasks[off + k];
+    row_value_offsets((const uint64_t *)g.s_bmps + off, m, g.row_val0[row], g.c_offs + c0, lane);
 }
 
 // C tile of task 64 w (what the task-list block-MAC kernels index per 64 tasks)
@@ -492,7 +519,8 @@ struct PublishStats {
 // scratch -> C's own arrays: one wave per block-row
 __global__ __launch_bounds__(kThreads) void rowmerge_emit_kernel(const uint32_t *__restrict__ tmp_off, const uint32_t *__restrict__ t_cols,
                                                                   const uint64_t *__restrict__ t_bmps, const uint32_t *__restrict__ c_rowptr,
-                                                                  uint32_t block_rows, uint64_t *__restrict__ c_keys, uint64_t *__restrict__ c_bmps)
+                                                                  const uint64_t *__restrict__ row_val0, uint32_t block_rows,
+                                                                  uint64_t *__restrict__ c_keys, uint64_t *__restrict__ c_bmps, uint64_t *__restrict__ c_offs)
 {
     const uint32_t row = blockIdx.x * 4 + (uint32_t)wave_id();
     if (row >= block_rows) return;
@@ -501,14 +529,26 @@ __global__ __launch_bounds__(kThreads) void rowmerge_emit_kernel(const uint32_t 
         c_keys[c0 + p] = key_make(row, t_cols[t0 + p]);
         c_bmps[c0 + p] = t_bmps[t0 + p];
     }
+    row_value_offsets(t_bmps + t0, n, row_val0[row], c_offs + c0, lane_id());
 }
+
+struct Cnt64In {
+    const uint32_t *cnt;
+    uint64_t rows;
+    __device__ uint64_t operator()(uint64_t i) const { return i < rows ? (uint64_t)cnt[i] : 0ull; }
+};
+struct SetU64 {
+    uint64_t *p;
+    uint64_t v;
+    __device__ void operator()(uint64_t) const { *p = v; }
+};
 
 }  // namespace
 
 // C's structure (keys, bitmaps, block-row pointer, block count) of A x B by the row-merge pass.  first_pos = T_2's exclusive scan of the
 // fan-out per A tile (n_a + 1 entries), total = its last element.  false: some block-row of C holds more tiles than the pass accepts
-// (nothing of C was allocated; the caller runs the pipeline).  true: C->keys / bmps / rowptr / block_num / max_row_blocks are set,
-// *surviving = candidate pairs that passed the bitmap filter.
+// (nothing of C was allocated; the caller runs the pipeline).  true: C->keys / bmps / offsets / nnz / rowptr / block_num / max_row_blocks
+// are set (the value array is the caller's to allocate), *surviving = candidate pairs that passed the bitmap filter.
 bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, uint32_t row_cap,
                        uint64_t *surviving, hipStream_t st)
 {
@@ -519,7 +559,8 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     ensure_rowptr(B, st);
     const uint64_t slots = std::min<uint64_t>(total, rows * (uint64_t)row_cap);
     if (slots >= (1ull << 31)) return false;
-    DevBuf<uint32_t> tmp_off(rows + 1), cnt(rows + 1), surv_row(rows), t_cols(slots);
+    DevBuf<uint32_t> tmp_off(rows + 1), cnt(rows + 1), surv_row(rows), nnz_row(rows + 1), t_cols(slots);
+    DevBuf<uint64_t> row_val0(rows + 1);
     DevBuf<uint64_t> t_bmps(slots);
     DevBuf<unsigned long long> acc(3);  // [0] surviving pairs, [1] most C tiles in a block-row, [2] overflow flag
     BMSP_HIP(hipMemsetAsync(acc.p, 0, 24, st));
@@ -529,20 +570,22 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     g.b_keys = B->keys; g.b_bmps = B->bmps; g.b_rowptr = B->rowptr;
     g.block_rows = (uint32_t)rows; g.b_block_rows = (uint32_t)B->num_block_rows(); g.row_cap = row_cap;
     g.tmp_off = tmp_off.p; g.t_cols = t_cols.p; g.t_bmps = t_bmps.p; g.cnt = cnt.p;
-    g.surv = surv_row.p; g.overflow = (uint32_t *)(acc.p + 2);
+    g.surv = surv_row.p; g.nnz = nnz_row.p; g.overflow = (uint32_t *)(acc.p + 2);
     hipLaunchKernelGGL(rowmerge_symbolic_kernel<1>, dim3((uint32_t)((rows + 3) / 4)), dim3(kThreads), 0, st, g);
     BMSP_CHECK_LAUNCH();
     uint32_t *c_rowptr = (uint32_t *)pool_alloc(sizeof(uint32_t) * (size_t)(rows + 1));
     HostScalar<uint32_t> c_size_h;
-    HostScalar<uint64_t> surv_h, mo_h;
+    HostScalar<uint64_t> surv_h, mo_h, nnz_h;
     uint32_t c_size = 0;
-    uint64_t mo = 0;
+    uint64_t mo = 0, c_nnz = 0;
     try {
         device_exclusive_scan<uint32_t>(CntIn{cnt.p, rows}, PtrOutTotal<uint32_t>{c_rowptr, rows, c_size_h.dev()}, rows + 1, st);
+        device_exclusive_scan<uint64_t>(Cnt64In{nnz_row.p, rows}, PtrOutTotal<uint64_t>{row_val0.p, rows, nnz_h.dev()}, rows + 1, st);
         device_max_sum(CntSurvIn{surv_row.p}, rows, (unsigned long long *)nullptr, acc.p, st);
         device_max_sum(CntSurvIn{cnt.p}, rows, acc.p + 1, (unsigned long long *)nullptr, st);
         device_for_each(PublishStats{acc.p, g.overflow, surv_h.dev(), mo_h.dev()}, 1, st);
         c_size = c_size_h.wait(st);
+        c_nnz = nnz_h.wait(st);
         *surviving = surv_h.wait(st);
         mo = mo_h.wait(st);
     } catch (...) {
@@ -559,9 +602,12 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     C->max_row_blocks = (int64_t)(uint32_t)mo;
     C->keys = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
     C->bmps = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
+    C->offsets = (uint64_t *)pool_alloc(8 * ((size_t)c_size + 1));
+    C->nnz = (int64_t)c_nnz;
+    device_for_each(SetU64{C->offsets + c_size, c_nnz}, 1, st);
     if (c_size) {
-        hipLaunchKernelGGL(rowmerge_emit_kernel, dim3((uint32_t)((rows + 3) / 4)), dim3(kThreads), 0, st, tmp_off.p, t_cols.p, t_bmps.p, c_rowptr,
-                           (uint32_t)rows, C->keys, C->bmps);
+        hipLaunchKernelGGL(rowmerge_emit_kernel, dim3((uint32_t)((rows + 3) / 4)), dim3(kThreads), 0, st, tmp_off.p, t_cols.p, t_bmps.p, c_rowptr, row_val0.p,
+                           (uint32_t)rows, C->keys, C->bmps, C->offsets);
         BMSP_CHECK_LAUNCH();
     }
     return true;
@@ -593,7 +639,8 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     if (total * 42 > (16ull << 30)) return false;  // scratch: 42 bytes per candidate pair
     ensure_rowptr(A, st);
     ensure_rowptr(B, st);
-    DevBuf<uint32_t> cnt(rows + 1), surv_row(rows + 1), row_task0(rows + 1), s_cols(total), s_begin(total);
+    DevBuf<uint32_t> cnt(rows + 1), surv_row(rows + 1), nnz_row(rows + 1), row_task0(rows + 1), s_cols(total), s_begin(total);
+    DevBuf<uint64_t> row_val0(rows + 1);
     DevBuf<uint64_t> s_surv(total), s_prod(total), s_tasks(total), s_bmps(total);
     DevBuf<uint16_t> s_ord(total);
     DevBuf<unsigned long long> acc(3);  // [1] most C tiles in a block-row, [2] overflow flag
@@ -601,7 +648,7 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     TaskListArgs g{};
     g.w = WalkArgs{A->keys, A->bmps, B->keys, B->bmps, B->rowptr, (uint32_t)B->num_block_rows()};
     g.a_rowptr = A->rowptr; g.first_pos = first_pos; g.block_rows = (uint32_t)rows;
-    g.cnt = cnt.p; g.surv = surv_row.p; g.overflow = (uint32_t *)(acc.p + 2);
+    g.cnt = cnt.p; g.surv = surv_row.p; g.nnz = nnz_row.p; g.overflow = (uint32_t *)(acc.p + 2);
     g.s_surv = s_surv.p; g.s_prod = s_prod.p; g.s_ord = s_ord.p; g.s_tasks = s_tasks.p; g.s_cols = s_cols.p; g.s_begin = s_begin.p;
     g.s_bmps = (unsigned long long *)s_bmps.p;
     const dim3 grid((uint32_t)((rows + 3) / 4));
@@ -610,16 +657,18 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     BMSP_CHECK_LAUNCH();
     uint32_t *c_rowptr = (uint32_t *)pool_alloc(sizeof(uint32_t) * (size_t)(rows + 1));
     HostScalar<uint32_t> c_size_h, n_tasks_h;
-    HostScalar<uint64_t> mo_h;
+    HostScalar<uint64_t> mo_h, nnz_h;
     uint32_t c_size = 0, n_tasks = 0;
-    uint64_t mo = 0;
+    uint64_t mo = 0, c_nnz = 0;
     try {
         device_exclusive_scan<uint32_t>(CntIn{cnt.p, rows}, PtrOutTotal<uint32_t>{c_rowptr, rows, c_size_h.dev()}, rows + 1, st);
         device_exclusive_scan<uint32_t>(CntIn{surv_row.p, rows}, PtrOutTotal<uint32_t>{row_task0.p, rows, n_tasks_h.dev()}, rows + 1, st);
+        device_exclusive_scan<uint64_t>(Cnt64In{nnz_row.p, rows}, PtrOutTotal<uint64_t>{row_val0.p, rows, nnz_h.dev()}, rows + 1, st);
         device_max_sum(CntSurvIn{cnt.p}, rows, acc.p + 1, (unsigned long long *)nullptr, st);
         device_for_each(PublishTaskStats{acc.p, mo_h.dev()}, 1, st);
         c_size = c_size_h.wait(st);
         n_tasks = n_tasks_h.wait(st);
+        c_nnz = nnz_h.wait(st);
         mo = mo_h.wait(st);
     } catch (...) {
         pool_free(c_rowptr);
@@ -635,6 +684,9 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     C->max_row_blocks = (int64_t)(uint32_t)mo;
     C->keys = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
     C->bmps = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
+    C->offsets = (uint64_t *)pool_alloc(8 * ((size_t)c_size + 1));
+    C->nnz = (int64_t)c_nnz;
+    device_for_each(SetU64{C->offsets + c_size, c_nnz}, 1, st);
     tasks.alloc(n_tasks);
     task_begin.alloc((size_t)c_size + 1);
     c_of_wave.alloc((size_t)n_tasks / 64 + 1);
@@ -642,7 +694,8 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     device_for_each(SetU32{task_begin.p + c_size, n_tasks}, 1, st);
     if (c_size) {
         g.c_rowptr = c_rowptr; g.row_task0 = row_task0.p;
-        g.c_keys = C->keys; g.c_bmps = C->bmps; g.task_begin = task_begin.p; g.tasks = tasks.p;
+        g.row_val0 = row_val0.p;
+        g.c_keys = C->keys; g.c_bmps = C->bmps; g.c_offs = C->offsets; g.task_begin = task_begin.p; g.tasks = tasks.p;
         hipLaunchKernelGGL(rowmerge_copy_kernel, grid, dim3(kThreads), 0, st, g);
         BMSP_CHECK_LAUNCH();
         device_for_each(COfWave{task_begin.p, c_size, c_of_wave.p}, ((uint64_t)n_tasks + 63) / 64, st);

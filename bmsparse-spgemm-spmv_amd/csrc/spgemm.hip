@@ -959,6 +959,10 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     auto finish_structure = [&]() -> uint64_t {
         const uint32_t c_size = (uint32_t)C->block_num;
         uint64_t c_nnz = 0;
+        if (C->offsets) {  // the row-merge passes write the offsets themselves (scan over block-rows + scan inside the block-row)
+            C->values = pool_alloc(dtype_size(C->dtype) * (size_t)(C->nnz ? C->nnz : 1));
+            return (uint64_t)C->nnz;
+        }
         C->offsets = (uint64_t *)pool_alloc(8 * ((size_t)c_size + 1));
         if (c_size) {
             HostScalar<uint64_t> c_nnz_h;
@@ -1044,8 +1048,8 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
                     return;
                 }
                 // C exists but a strip of it exceeds the kernel's column list: drop it
-                pool_free(C->keys); pool_free(C->bmps); pool_free(C->rowptr);
-                C->keys = nullptr; C->bmps = nullptr; C->rowptr = nullptr; C->rowptr_rows = 0; C->max_row_blocks = -1; C->block_num = 0;
+                pool_free(C->keys); pool_free(C->bmps); pool_free(C->rowptr); pool_free(C->offsets);
+                C->keys = nullptr; C->bmps = nullptr; C->rowptr = nullptr; C->offsets = nullptr; C->nnz = 0; C->rowptr_rows = 0; C->max_row_blocks = -1; C->block_num = 0;
             }
             tm.mark(-1);
         }
