@@ -288,6 +288,7 @@ void spgemm_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_mat
     bmsp_spgemm_stats ps{};  // this rank's panel (loopback: summed over the panels, like the paneled single-GPU product)
     for (int r : local_ranks(c)) {
         MatPtr view(row_panel(A, bounds[(size_t)r], bounds[(size_t)r + 1], st), free_matrix);
+        rm_hint_inherit(view.get(), A);
         bmsp_matrix_s *cp_raw = nullptr;
         bmsp_spgemm_stats one{};
         try {
@@ -295,6 +296,7 @@ void spgemm_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_mat
         } catch (const TaskRangeExceeded &) {  // a panel beyond one task list: run it in sub-panels (same answer)
             spgemm_paneled(view.get(), B, &cp_raw, mode, tc_version, verbose, st, &one);
         }
+        rm_hint_merge(A, view.get());
         cp[(size_t)r].reset(cp_raw);
         local[(size_t)r] = {cp_raw->block_num, cp_raw->nnz};
         ps.task_list_size += one.task_list_size; ps.bmp_reduction += one.bmp_reduction; ps.surviving_tasks += one.surviving_tasks;

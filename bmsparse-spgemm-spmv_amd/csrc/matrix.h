@@ -68,6 +68,20 @@ struct bmsp_comm_s {
 
 namespace bmsp {
 
+// A row-panel view inherits what its parent learned about a right operand (which row-merge mode the pair needs) and hands back what it
+// learned itself: views are made per call, and without this every panel product would pay for a pass that does not fit (hub block-rows).
+inline void rm_hint_inherit(bmsp_matrix_s *view, const bmsp_matrix_s *parent)
+{
+    view->rm_partner_keys = parent->rm_partner_keys; view->rm_partner_blocks = parent->rm_partner_blocks; view->rm_partner_mode = parent->rm_partner_mode;
+}
+inline void rm_hint_merge(bmsp_matrix_s *parent, const bmsp_matrix_s *view)
+{
+    if (!view->rm_partner_keys) return;
+    const bool same = parent->rm_partner_keys == view->rm_partner_keys && parent->rm_partner_blocks == view->rm_partner_blocks;
+    const int mode = same && parent->rm_partner_mode > view->rm_partner_mode ? parent->rm_partner_mode : view->rm_partner_mode;
+    parent->rm_partner_keys = view->rm_partner_keys; parent->rm_partner_blocks = view->rm_partner_blocks; parent->rm_partner_mode = mode;
+}
+
 inline size_t dtype_size(bmsp_dtype t) { return t == BMSP_F16 ? 2 : (t == BMSP_F32 ? 4 : 8); }
 
 // host COO triples produced by the MatrixMarket parser

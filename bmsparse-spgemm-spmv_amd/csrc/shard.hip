@@ -143,9 +143,11 @@ void spgemm_paneled(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, in
         partition_rows(A, B, parts, bounds.data(), st, nullptr);
         for (int p = 0; p < parts; p++) {
             std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> view(row_panel(A, bounds[(size_t)p], bounds[(size_t)p + 1], st), free_matrix);
+            rm_hint_inherit(view.get(), A);
             bmsp_matrix_s *cp = nullptr;
             bmsp_spgemm_stats ps{};
             spgemm(view.get(), B, &cp, mode, tc_version, verbose, st, &ps);  // a single hub block-row beyond the range still fails here
+            rm_hint_merge(A, view.get());
             panels.push_back(cp);
             acc.task_list_size += ps.task_list_size; acc.bmp_reduction += ps.bmp_reduction; acc.surviving_tasks += ps.surviving_tasks;
             acc.c_blocks += ps.c_blocks; acc.c_nnz += ps.c_nnz;
