@@ -813,6 +813,44 @@ def test_spgemm_fp32_exponent_range_keeps_v15(oracle, bmsp, scale):
         assert st["mac_variant"] == 3, st
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_spgemm_rowmerge_random_shapes(oracle, bmsp, monkeypatch, seed):
+    """Seeded random rectangular operands (ragged edges, empty block-rows and block-columns, clustered and scattered columns, explicit
+    duplicates, 1 ... ~40 tiles per block-row): whatever mode the library picks under sort mode 0 -- strip mode, task-list mode or the
+    pipeline -- every array of C and every stage counter equals the pipeline's (BMSP_SPGEMM_ROWMERGE=0) bit for bit, and for the V15
+    numerics the oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    m, k, n = (int(rng.integers(9, 700)) for _ in range(3))
+    dtype, tc = [(0, 5), (1, 4), (1, 5), (2, 5)][seed % 4]
+
+    def rand_coo(rows, cols, nnz, clustered):
+        r = rng.integers(0, rows, nnz)
+        if clustered:  # columns near a moving diagonal: few distinct C columns per block-row
+            c = np.clip((r * cols) // max(rows, 1) + rng.integers(-12, 13, nnz), 0, cols - 1)
+        else:
+            c = rng.integers(0, cols, nnz)
+        if seed % 3 == 0:  # some empty block-rows / block-columns
+            keep = ((r // 8) % 5 != 3) & ((c // 8) % 7 != 2)
+            r, c = r[keep], c[keep]
+        v = rng.integers(-4, 5, len(r)).astype(np.float64)
+        v[v == 0] = 1.0
+        return rows, cols, r, c, v
+
+    A = rand_coo(m, k, int(rng.integers(1, 12)) * m, seed % 2 == 0)
+    Bc = rand_coo(k, n, int(rng.integers(1, 12)) * k, seed % 4 < 2)
+    st = check_spgemm(oracle, bmsp, A, Bc, dtype, 0, tc, exact_expected=True)  # (small integers: exact on every path)
+    a = bmsp.BmSpMatrix.from_coo(*A, dtype=dtype)
+    b = bmsp.BmSpMatrix.from_coo(*Bc, transposed=True, dtype=dtype)
+    new, stn = bmsp.spgemm(a, b, tc_version=tc)
+    monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "0")
+    old, sto = bmsp.spgemm(a, b, tc_version=tc)
+    assert sto["sort_path"] in (0, 1)
+    for key in ("task_list_size", "bmp_reduction", "surviving_tasks", "c_blocks", "c_nnz"):
+        assert stn[key] == sto[key] == st[key], key
+    for x, y in zip(old.host_arrays(), new.host_arrays()):
+        np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("case", ["rmat", "banded", "filtered", "rect"])
 def test_spgemm_single_pass_expansion(oracle, bmsp, monkeypatch, case):
     """BMSP_EXPAND_LOOKBACK: T_3 + T_4 as one decoupled look-back pass (survivors written at the running prefix of the earlier tiles);
