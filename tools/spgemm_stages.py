@@ -11,10 +11,11 @@ cases = [("fem_like(47,27pt)", lambda: gen.fem_like(47, "27pt")), ("cage_like(13
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 quick = "--quick" in sys.argv
 fp32 = "--fp32" in sys.argv  # with --quick: the fp32 V15 configuration instead of the fp16 MFMA one
+half5 = "--half5" in sys.argv  # with --quick: fp16 operands with V15 numerics (tc_version 5: the reference's default configuration)
 cases = [c for c in cases if args[0] in c[0]] if args else cases[:-1]
 for name, mk in cases:
     n, _, r, c, v = mk()
-    for dtype, tc in ((((B.F32, 5),) if fp32 else ((B.F16, 4),)) if quick else ((B.F32, 5), (B.F16, 5), (B.F16, 4))):
+    for dtype, tc in ((((B.F32, 5),) if fp32 else ((B.F16, 5),) if half5 else ((B.F16, 4),)) if quick else ((B.F32, 5), (B.F16, 5), (B.F16, 4))):
         A = B.BmSpMatrix.from_coo(n, n, r, c, v, dtype=dtype).prepare(2)
         At = B.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=dtype).prepare(2)
         for mode in ((0,) if quick else (2, 1, 0)):
