@@ -599,6 +599,20 @@ int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, in
     BMSP_API_END
 }
 
+int bmsp_spgemm_symbolic(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, void *stream, bmsp_spgemm_stats *stats)
+{
+    BMSP_API_BEGIN
+    spgemm(A, B, C, mode, tc_version, 0, as_stream(stream), stats, true);
+    BMSP_API_END
+}
+
+int bmsp_spgemm_numeric(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t C, int tc_version, void *stream, bmsp_spgemm_stats *stats)
+{
+    BMSP_API_BEGIN
+    spgemm_numeric(A, B, C, tc_version, as_stream(stream), stats);
+    BMSP_API_END
+}
+
 int bmsp_segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const int *d_segs, int64_t num_segs, void *stream)
 {
     BMSP_API_BEGIN

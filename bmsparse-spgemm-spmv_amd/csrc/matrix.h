@@ -139,7 +139,8 @@ void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st,
 void spmv_launch_info(bmsp_matrix_s *A, int variant, hipStream_t st, char *kernel, size_t kernel_cap, int64_t *compulsory, int64_t *format_bytes);
 void spmm(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, int k, hipStream_t st);
 void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int tc_version, int verbose, hipStream_t st,
-            bmsp_spgemm_stats *stats);
+            bmsp_spgemm_stats *stats, bool structure_only = false);
+void spgemm_numeric(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc_version, hipStream_t st, bmsp_spgemm_stats *stats);
 template <typename T>
 struct PingPong;
 // stable sort of (key, task) pairs inside the runs of equal (key >> jbits): the SpGEMM's segmented path

@@ -915,7 +915,7 @@ void print_stage(bool verbose, const char *name, double us)
 }  // namespace
 
 void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, int tc_version, int verbose, hipStream_t st,
-            bmsp_spgemm_stats *stats)
+            bmsp_spgemm_stats *stats, bool structure_only)
 {
     if (!A || !B || !Cout) fail(BMSP_ERR_INVALID, "null argument");
     if (A->transposed) fail(BMSP_ERR_INVALID, "A must be built with transposed=0");
@@ -1038,10 +1038,12 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
                     S->sort_path = BMSP_SORT_PATH_ROWMERGE;
                     finish_structure();
                     tm.mark(9);
-                    if (C->block_num) {
+                    if (C->block_num && !structure_only) {
                         launch_mac_strip(A, B, C.get(), st);
                         S->mac_variant = BMSP_MAC_STRIP;
                         S->mac_kernel = mfma ? tc_version : 5;
+                    } else if (C->nnz) {
+                        BMSP_HIP(hipMemsetAsync(C->values, 0, dtype_size(C->dtype) * (size_t)C->nnz, st));  // bmsp_spgemm_symbolic: structure only
                     }
                     tm.mark(7);
                     finish();
@@ -1188,7 +1190,9 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     }  // (expand - sort - compress)
 
     // T_7: block multiply-accumulate
-    if (c_size) {
+    if (structure_only) {
+        if (C->nnz) BMSP_HIP(hipMemsetAsync(C->values, 0, dtype_size(C->dtype) * (size_t)C->nnz, st));  // bmsp_spgemm_symbolic
+    } else if (c_size) {
         if (mfma) {
             if ((uint64_t)A->values_extent() * 2 + 16 >= (1ull << 32) || (uint64_t)B->values_extent() * 2 + 16 >= (1ull << 32))
                 fail(BMSP_ERR_LIMIT, "MFMA block-MAC addresses operand values through 4 GiB buffer descriptors; use tc_version 5");
@@ -1231,6 +1235,62 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     }
     tm.mark(7);
     finish();
+}
+
+namespace {
+struct StructDiff {
+    const uint64_t *k0, *b0, *k1, *b1;
+    uint32_t *flag;
+    __device__ void operator()(uint64_t i) const
+    {
+        if (k0[i] != k1[i] || b0[i] != b1[i]) *flag = 1u;
+    }
+};
+}  // namespace
+
+// The numeric stage alone (bmsp_spgemm_numeric): C already holds the structure of A x B -- from bmsp_spgemm or bmsp_spgemm_symbolic on
+// operands of the same structure -- and receives the values of A x B in place.  Where a strip kernel applies (it needs C's structure and
+// the operands, no task list) that is T_7 and nothing else; otherwise the whole product runs and its values are copied over after its
+// structure was checked against C's.
+void spgemm_numeric(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc_version, hipStream_t st, bmsp_spgemm_stats *stats)
+{
+    if (!A || !B || !C) fail(BMSP_ERR_INVALID, "null argument");
+    if (A->transposed || !B->transposed || C->transposed) fail(BMSP_ERR_INVALID, "layouts: A and C normal, B transposed");
+    if (A->num_cols != B->num_rows || C->num_rows != A->num_rows || C->num_cols != B->num_cols) fail(BMSP_ERR_INVALID, "shape mismatch");
+    if (A->dtype != B->dtype || C->dtype != (A->dtype == BMSP_F64 ? BMSP_F64 : BMSP_F32)) fail(BMSP_ERR_INVALID, "value types: A, B alike; C fp32 (fp64 for fp64 operands)");
+    if (tc_version < 1 || tc_version > 5) fail(BMSP_ERR_INVALID, "tc_version must be 1..5");
+    if (C->ownership == 2 && C->view_block_begin) fail(BMSP_ERR_UNSUPPORTED, "C must not be a row-panel view");
+    bmsp_spgemm_stats local{};
+    bmsp_spgemm_stats *S = stats ? stats : &local;
+    *S = bmsp_spgemm_stats{};
+    const bool mfma = tc_version != 5 && A->dtype == BMSP_F16;
+    const bool strip_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || A->dtype == BMSP_F32;
+    const char *sf = getenv("BMSP_MAC_STRIP");
+    if (C->block_num && strip_numeric && !(sf && sf[0] == '0') && mac_strip_operands_ok(A, B, st) && mac_strip_fits_c(C, st)) {
+        StageTimer tm(st, true);
+        tm.mark(-1);
+        launch_mac_strip(A, B, C, st);
+        tm.mark(7);
+        BMSP_HIP(hipStreamSynchronize(st));
+        S->t_us[0] = tm.collect(S->t_us);
+        S->mac_variant = BMSP_MAC_STRIP;
+        S->mac_kernel = mfma ? tc_version : 5;
+        S->c_blocks = C->block_num; S->c_nnz = C->nnz;
+        return;
+    }
+    bmsp_matrix_s *full_raw = nullptr;
+    spgemm(A, B, &full_raw, BMSP_SORT_AUTO, tc_version, 0, st, S);
+    std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> full(full_raw, free_matrix);
+    bool same = full->block_num == C->block_num && full->nnz == C->nnz;
+    if (same && C->block_num) {
+        DevBuf<uint32_t> flag(1);
+        BMSP_HIP(hipMemsetAsync(flag.p, 0, 4, st));
+        device_for_each(StructDiff{full->keys, full->bmps, C->keys, C->bmps, flag.p}, (uint64_t)C->block_num, st);
+        same = read_back(flag.p, st) == 0u;
+    }
+    if (!same) fail(BMSP_ERR_INVALID, "C does not hold the structure of A x B (%lld blocks / %lld values expected)", (long long)full->block_num, (long long)full->nnz);
+    if (C->nnz) BMSP_HIP(hipMemcpyAsync(C->values, full->values, dtype_size(C->dtype) * (size_t)C->nnz, hipMemcpyDeviceToDevice, st));
+    BMSP_HIP(hipStreamSynchronize(st));
 }
 
 }  // namespace bmsp

@@ -27,7 +27,7 @@ SYMBOLS = [
     "bmsp_event_create", "bmsp_event_record", "bmsp_event_elapsed_ms", "bmsp_event_destroy",
     "bmsp_matrix_from_mtx", "bmsp_matrix_from_coo", "bmsp_matrix_from_coo_device", "bmsp_matrix_from_arrays",
     "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_prepare", "bmsp_matrix_invalidate", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
-    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmv_launch_info", "bmsp_spmm", "bmsp_spgemm", "bmsp_selftest_mfma_layout", "bmsp_selftest_mfma_f32_chain", "bmsp_segsort_u64",
+    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmv_launch_info", "bmsp_spmm", "bmsp_spgemm", "bmsp_spgemm_symbolic", "bmsp_spgemm_numeric", "bmsp_selftest_mfma_layout", "bmsp_selftest_mfma_f32_chain", "bmsp_segsort_u64",
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
     "bmsp_comm_unique_id", "bmsp_comm_init", "bmsp_comm_init_from_env", "bmsp_comm_init_loopback", "bmsp_shard_layout", "bmsp_shard_row_slices", "bmsp_comm_info", "bmsp_comm_free", "bmsp_spgemm_sharded", "bmsp_spmv_sharded",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
@@ -110,6 +110,8 @@ def lib():
         L.bmsp_spmm.argtypes = [vp, vp, i64, vp, i64, i, vp]
         L.bmsp_spmv_launch_info.argtypes = [vp, i, C.c_char_p, C.c_size_t, p(i64), p(i64)]
         L.bmsp_spgemm.argtypes = [vp, vp, p(vp), i, i, i, vp, p(SpgemmStats)]
+        L.bmsp_spgemm_symbolic.argtypes = [vp, vp, p(vp), i, i, vp, p(SpgemmStats)]
+        L.bmsp_spgemm_numeric.argtypes = [vp, vp, vp, i, vp, p(SpgemmStats)]
         L.bmsp_selftest_mfma_layout.argtypes = [p(i)]
         L.bmsp_selftest_mfma_f32_chain.argtypes = [p(i)]
         L.bmsp_segsort_u64.argtypes = [vp, vp, i, i64, vp, i64, vp]
@@ -432,6 +434,21 @@ def spgemm(A, B, mode=SORT_AUTO, tc_version=5, verbose=False, stream=None):
     st = SpgemmStats()
     check(lib().bmsp_spgemm(A.h, B.h, C.byref(h), int(mode), int(tc_version), int(bool(verbose)), stream, C.byref(st)))
     return BmSpMatrix(h.value), st.as_dict()
+
+
+def spgemm_symbolic(A, B, mode=SORT_AUTO, tc_version=5, stream=None):
+    """C's structure only (values allocated, zero): bmsp_spgemm_symbolic"""
+    h = C.c_void_p()
+    st = SpgemmStats()
+    check(lib().bmsp_spgemm_symbolic(A.h, B.h, C.byref(h), int(mode), int(tc_version), stream, C.byref(st)))
+    return BmSpMatrix(h.value), st.as_dict()
+
+
+def spgemm_numeric(A, B, Cm, tc_version=5, stream=None):
+    """the values of A x B into a C that already holds the product's structure: bmsp_spgemm_numeric"""
+    st = SpgemmStats()
+    check(lib().bmsp_spgemm_numeric(A.h, B.h, Cm.h, int(tc_version), stream, C.byref(st)))
+    return st.as_dict()
 
 
 # bb_segsort(keys, vals, n, segs, length)

@@ -249,6 +249,23 @@ inline void bmSparse_mult(bmSpMatrix<valueIn> &A, bmSpMatrix<valueIn> &B, bmSpMa
     std::printf("Toda F: %lld \xce\xbcs \n", (long long)(st.t_us[0] + 0.5)); /* :1220 */
 }
 
+/* The two halves of bmSparse_mult for repeated products on one sparsity pattern (bmsp_spgemm_symbolic / bmsp_spgemm_numeric; the reference
+ * runs both halves in every call, src/bmSparse_SPGEMM.cu:849-1158): _symbolic leaves C with the product's structure and zero values,
+ * _numeric overwrites the values of a C of that structure with those of A x B. */
+template <class valueIn, class valueOut>
+inline void bmSparse_mult_symbolic(bmSpMatrix<valueIn> &A, bmSpMatrix<valueIn> &B, bmSpMatrix<valueOut> &C, bool mode, long tc_version,
+                                   bmsp_spgemm_stats *stats = nullptr)
+{
+    bmsp_matrix_t c = nullptr;
+    bmsp::check(bmsp_spgemm_symbolic(A.handle(), B.handle(), &c, mode ? BMSP_SORT_SEGMENTED : BMSP_SORT_AUTO, (int)tc_version, nullptr, stats));
+    C.reset(c);
+}
+template <class valueIn, class valueOut>
+inline void bmSparse_mult_numeric(bmSpMatrix<valueIn> &A, bmSpMatrix<valueIn> &B, bmSpMatrix<valueOut> &C, long tc_version, bmsp_spgemm_stats *stats = nullptr)
+{
+    bmsp::check(bmsp_spgemm_numeric(A.handle(), B.handle(), C.handle(), (int)tc_version, nullptr, stats));
+}
+
 /* The same product sharded over one process per GPU (bmsp_spgemm_sharded): every rank passes the same A and B, multiplies
  * its block-row panel of A and returns the whole C. */
 template <class valueIn, class valueOut>

@@ -223,6 +223,20 @@ typedef struct {
 int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, int verbose,
                 void *stream, bmsp_spgemm_stats *stats);
 
+/* The two halves of bmsp_spgemm for callers that multiply the same sparsity pattern again and again (new values in A / B, same
+ * structure: time stepping, AMG set-ups).  The reference has one entry point, bmSparse_mult, whose stages T_1 ... T_9 are the symbolic half
+ * (src/bmSparse_SPGEMM.cu:849-1107: C's keys, bitmaps, offsets, nnz) and T_7 the numeric half (:1109-1158).
+ *   bmsp_spgemm_symbolic: C's structure only; *C's values are allocated and zero.  Same arguments as bmsp_spgemm otherwise.
+ *   bmsp_spgemm_numeric : C must hold the structure of A x B (from bmsp_spgemm / _symbolic on operands of the SAME structure); its values
+ *                         are overwritten with those of A x B under tc_version's numerics -- exactly what bmsp_spgemm would store.  Where a
+ *                         strip block-MAC applies (fp16 operands with tc_version 4, fp32 operands; block-rows of C of at most 256 tiles)
+ *                         only that kernel runs; otherwise the whole product runs, its structure is checked against C's
+ *                         (BMSP_ERR_INVALID on a mismatch) and its values are copied.  After changing an operand's values in place call
+ *                         bmsp_matrix_invalidate(m, 0) first (cached tile copies). */
+int bmsp_spgemm_symbolic(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, void *stream,
+                         bmsp_spgemm_stats *stats);
+int bmsp_spgemm_numeric(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t C, int tc_version, void *stream, bmsp_spgemm_stats *stats);
+
 /* Hardware self test of the operand / result lane layout the K = 32 block-MAC relies on (v_mfma_f32_16x16x32_f16: lane l holds
  * A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15], D[4*(l>>4)+i][l&15]): one 16x16x32 product of asymmetric small integers against a host
  * loop.  *mismatches = number of wrong elements (0 on gfx950).  The reference's analogue is the fragment-layout assumption of

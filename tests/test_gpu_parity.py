@@ -813,6 +813,51 @@ def test_spgemm_fp32_exponent_range_keeps_v15(oracle, bmsp, scale):
         assert st["mac_variant"] == 3, st
 
 
+@pytest.mark.parametrize("case,dtype,tc", [("fem", 0, 5), ("fem", 1, 4), ("banded64", 1, 4), ("rect_ragged", 0, 5), ("fem", 2, 5), ("fem", 1, 5),
+                                           ("rmat_hub", 1, 4)])
+def test_spgemm_symbolic_numeric_split(oracle, bmsp, case, dtype, tc):
+    """bmsp_spgemm_symbolic gives the product's structure with zero values; bmsp_spgemm_numeric fills a C of that structure with the
+    values bmsp_spgemm would store -- bit for bit -- also for NEW operand values on the same structure (the use the split exists for),
+    whether a strip kernel does it alone (fp16 tc 4, fp32) or the whole product runs behind it (fp64, fp16 V15, hub rows).  A C of a
+    different structure is refused."""
+    from pybmsp import gen
+    if case == "rmat_hub":
+        n, _, r, c, v = gen.rmat(11, 8)
+        A = Bc = (n, n, r, c, np.round(v * 8) / 8)
+    else:
+        A, Bc, _ = _strip_case(gen, oracle, case)
+        if Bc is None:
+            Bc = A
+    a = bmsp.BmSpMatrix.from_coo(*A, dtype=dtype)
+    b = bmsp.BmSpMatrix.from_coo(*Bc, transposed=True, dtype=dtype)
+    full, stf = bmsp.spgemm(a, b, tc_version=tc)
+    sym, sts = bmsp.spgemm_symbolic(a, b, tc_version=tc)
+    kf, bf, of, vf = full.host_arrays()
+    ks, bs, os_, vs = sym.host_arrays()
+    np.testing.assert_array_equal(kf, ks); np.testing.assert_array_equal(bf, bs); np.testing.assert_array_equal(of, os_)
+    assert not vs.any() and sts["c_nnz"] == stf["c_nnz"] and sts["surviving_tasks"] == stf["surviving_tasks"]
+    stn = bmsp.spgemm_numeric(a, b, sym, tc_version=tc)
+    np.testing.assert_array_equal(sym.host_arrays()[3], vf)
+    if (dtype == 0 or (dtype == 1 and tc == 4)) and case != "rmat_hub":
+        assert stn["mac_variant"] == 3, stn  # the strip kernel alone
+    # new values, same structure
+    A2 = A[:4] + (np.asarray(A[4]) * 0.5,)
+    B2 = Bc[:4] + (np.asarray(Bc[4]) * -2.0,)
+    a2 = bmsp.BmSpMatrix.from_coo(*A2, dtype=dtype)
+    b2 = bmsp.BmSpMatrix.from_coo(*B2, transposed=True, dtype=dtype)
+    full2, _ = bmsp.spgemm(a2, b2, tc_version=tc)
+    bmsp.spgemm_numeric(a2, b2, sym, tc_version=tc)
+    np.testing.assert_array_equal(sym.host_arrays()[3], full2.host_arrays()[3])
+    # a C of another structure
+    if case == "fem":
+        n2, _, r2, c2, v2 = gen.banded(A[0], 3)
+        other, _ = bmsp.spgemm(bmsp.BmSpMatrix.from_coo(n2, n2, r2, c2, v2, dtype=dtype), bmsp.BmSpMatrix.from_coo(n2, n2, r2, c2, v2, transposed=True, dtype=dtype),
+                               tc_version=tc)
+        if dtype == 2 or (dtype == 1 and tc == 5):  # (the checked path; the strip kernels trust the caller, as the header says)
+            with pytest.raises(Exception):
+                bmsp.spgemm_numeric(a, b, other, tc_version=tc)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_spgemm_rowmerge_random_shapes(oracle, bmsp, monkeypatch, seed):
     """Seeded random rectangular operands (ragged edges, empty block-rows and block-columns, clustered and scattered columns, explicit
