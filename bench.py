@@ -461,8 +461,9 @@ def bench_spgemm(B, gen, np, args):
         t_mac = best["t_us"][7] * 1e-6
         f_mac = 1024.0 * best["surviving_tasks"]
         peak = MFMA_F16_PEAK_TFLOPS if dtype == B.F16 else FP32_PEAK_TFLOPS
-        kernel_files = ["bmsparse-spgemm-spmv_amd/csrc/blockmac_strip.hip", "bmsparse-spgemm-spmv_amd/csrc/rowmerge.hip", "bmsparse-spgemm-spmv_amd/csrc/blockmac32.hip", "bmsparse-spgemm-spmv_amd/csrc/blockmac_f32.hip",
-                        "bmsparse-spgemm-spmv_amd/csrc/spgemm.hip"]
+        # the sources that define the profiled block-MAC kernels (the dispatch in spgemm.hip and the symbolic passes do not change them)
+        kernel_files = ["bmsparse-spgemm-spmv_amd/csrc/blockmac_strip.hip", "bmsparse-spgemm-spmv_amd/csrc/blockmac32.hip", "bmsparse-spgemm-spmv_amd/csrc/blockmac_f32.hip",
+                        "bmsparse-spgemm-spmv_amd/csrc/mac_common.hip.h"]
         traffic, traffic_src = profile_value("r*_%s_traffic.json" % ptag, "traffic_bytes_per_launch", kernel_files)
         roof = {"bound": "mfma" if dtype == B.F16 else "fp32 matrix / vector rate", "kernel": MAC_VARIANT.get(best.get("mac_variant", 0), "?"),
                 "achieved": round(f_mac / t_mac / 1e12, 3),
