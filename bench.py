@@ -456,6 +456,24 @@ def bench_spgemm(B, gen, np, args):
             del Cm
         runs.sort(key=lambda q: q["t_us"][0])
         best = runs[len(runs) // 2]
+        # the numeric half alone on a C that already has the structure (bmsp_spgemm_numeric: new values on an old pattern)
+        numeric_ms = None
+        try:
+            Cs, _ = B.spgemm_symbolic(A, At, mode=B.SORT_AUTO, tc_version=tc)
+            nm = []
+            for it in range(4):
+                B.synchronize()
+                t0 = time.perf_counter()
+                stn = B.spgemm_numeric(A, At, Cs, tc_version=tc)
+                B.synchronize()
+                if it:
+                    nm.append(((time.perf_counter() - t0) * 1e3, stn["mac_variant"]))
+            nm.sort()
+            numeric_ms = {"wall_ms": round(nm[len(nm) // 2][0], 3), "kernel": MAC_VARIANT.get(nm[0][1], "?"),
+                          "note": "bmsp_spgemm_numeric into an existing structure; the strip kernel alone where it applies, else the whole product + a value copy"}
+            del Cs
+        except Exception as e:  # an extra: never lose the line over it
+            numeric_ms = {"error": "%s: %s" % (type(e).__name__, e)}
         P = scalar_products(np, A)
         t_total = best["t_us"][0] * 1e-6
         t_mac = best["t_us"][7] * 1e-6
@@ -483,7 +501,7 @@ def bench_spgemm(B, gen, np, args):
                     "tasks_per_c_block": round(best["surviving_tasks"] / max(1, best["c_blocks"]), 2),
                     "c_nnz": best["c_nnz"], "scalar_products": int(P), "total_ms": round(t_total * 1e3, 3), "timing": "median of %d products (device time of the whole call)" % len(runs),
                     "wall_ms": round(best["wall_ms"], 3), "prepare_ms": round(prepare_ms, 3), "first_call_ms": round(first_call_ms, 3),
-                    "total_with_prepare_ms": round(t_total * 1e3 + prepare_ms, 3),
+                    "total_with_prepare_ms": round(t_total * 1e3 + prepare_ms, 3), "numeric_only": numeric_ms,
                     "prepare_note": "prepare = bmsp_matrix_prepare of both operands (host wall time); first_call = the first product after it (cold pool)",
                     "gflops": round(2.0 * P / t_total / 1e9, 2),
                     "gflops_with_prepare": round(2.0 * P / (t_total + prepare_ms * 1e-3) / 1e9, 2),
