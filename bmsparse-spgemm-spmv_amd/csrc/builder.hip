@@ -378,6 +378,7 @@ void free_matrix(bmsp_matrix_s *m)
     pool_free(m->block_meta);
     pool_free(m->dense_tiles);
     pool_free(m->lane_tiles);
+    pool_free(m->sp_tasks); pool_free(m->sp_task_begin); pool_free(m->sp_c_of_wave);
     free_matrix(m->shard_view);
     delete m;
 }
@@ -395,6 +396,8 @@ void invalidate_matrix(bmsp_matrix_s *m, int structure_changed)
     if (!structure_changed) return;
     pool_free(m->rowptr); m->rowptr = nullptr; m->rowptr_rows = 0; m->max_row_blocks = -1;
     m->rm_partner_keys = nullptr; m->rm_partner_blocks = 0; m->rm_partner_mode = 0;
+    pool_free(m->sp_tasks); pool_free(m->sp_task_begin); pool_free(m->sp_c_of_wave);
+    m->sp_tasks = nullptr; m->sp_task_begin = nullptr; m->sp_c_of_wave = nullptr; m->sp_n_tasks = 0;
     pool_free(m->spmv_chunks); m->spmv_chunks = nullptr; m->spmv_num_chunks = 0; m->spmv_plan_long = 0; m->spmv_full_tiles = 0;
     pool_free(m->spmv_pos); m->spmv_pos = nullptr; m->spmv_tinfo = nullptr; m->spmv_eoff = nullptr; m->spmv_pos_base = 0; m->spmv_pos_count = 0; m->spmv_pos_tried = 0;
     pool_free(m->block_meta); m->block_meta = nullptr;

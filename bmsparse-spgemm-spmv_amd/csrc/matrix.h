@@ -43,6 +43,11 @@ struct bmsp_matrix_s {
     const void *rm_partner_keys = nullptr;
     int64_t rm_partner_blocks = 0;
     int rm_partner_mode = 0;
+    // a product made by bmsp_spgemm_symbolic keeps its sorted task list for bmsp_spgemm_numeric (T_7 alone on new operand values)
+    uint64_t *sp_tasks = nullptr;
+    uint32_t *sp_task_begin = nullptr, *sp_c_of_wave = nullptr;
+    uint64_t sp_n_tasks = 0, sp_candidates = 0;
+    int64_t sp_a_blocks = 0, sp_b_blocks = 0;
     int values_finite = -1;
     int f32_exp_min = 255, f32_exp_max = 0;  // fp32: biased exponent range of the non-zero stored values (with values_finite)       // fp16 operands of the strip block-MAC: 1 = no inf / NaN stored (-1 = not looked yet)
     // a row-panel view points into its parent

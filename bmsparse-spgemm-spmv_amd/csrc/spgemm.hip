@@ -914,6 +914,53 @@ void print_stage(bool verbose, const char *name, double us)
 
 }  // namespace
 
+// T_7 from a sorted task list: the block multiply-accumulate kernel of the tc_version and value type (shared by the whole product and by
+// bmsp_spgemm_numeric on a C that kept its list)
+static void launch_block_mac(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *tasks_sorted, uint64_t n_tasks, const uint32_t *task_begin,
+                             const uint32_t *c_of_wave, uint64_t total, int tc_version, bool mfma, bmsp_spgemm_stats *S, hipStream_t st)
+{
+    const uint32_t c_size = (uint32_t)C->block_num;
+    if (mfma) {
+        if ((uint64_t)A->values_extent() * 2 + 16 >= (1ull << 32) || (uint64_t)B->values_extent() * 2 + 16 >= (1ull << 32))
+            fail(BMSP_ERR_LIMIT, "MFMA block-MAC addresses operand values through 4 GiB buffer descriptors; use tc_version 5");
+        // the group kernel's 12-byte value loads may run past the last stored value: arrays from this library's
+        // allocator carry that slack (runtime.h), borrowed arrays (bmsp_matrix_from_arrays, ownership 2) may not
+        const uint32_t a_bytes = (uint32_t)(A->values_extent() * 2), b_bytes = (uint32_t)(B->values_extent() * 2);
+        const bool old_mac = getenv("BMSP_MAC_OLD") != nullptr;  // experiment switch: the r1 16x16x16 group kernel
+        if (tc_version == 4 && !old_mac && mac_mfma32_supported(A, B)) {
+            // many tasks per C tile and most candidate pairs alive: the strip kernel (operand reuse; reads A, B, C, not the task list)
+            if (mac_strip_eligible(A, B, C, total, n_tasks, st)) {
+                launch_mac_strip(A, B, C, st);
+                S->mac_variant = BMSP_MAC_STRIP;
+            } else {
+                S->mac_variant = launch_mac_mfma32(tasks_sorted, n_tasks, task_begin, c_of_wave, A, B, C, st);
+            }
+        } else if (tc_version == 4 && pool_owns(A->values) && pool_owns(B->values) && A->block_num < (1ll << 28) && B->block_num < (1ll << 28)) {
+            ensure_block_meta(A, st);
+            ensure_block_meta(B, st);
+            uint32_t groups = (c_size + kGroupC - 1) / kGroupC;
+            uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
+            hipLaunchKernelGGL(block_mac_mfma_f16_group_kernel, dim3(grid), dim3(kThreads), 0, st, tasks_sorted, task_begin, A->block_meta,
+                               (uint32_t)(A->block_num * 16), (const _Float16 *)A->values, B->block_meta, (uint32_t)(B->block_num * 16),
+                               (const _Float16 *)B->values, C->bmps, C->offsets, (float *)C->values, c_size, a_bytes + 16u, b_bytes + 16u);
+        } else {
+            uint32_t groups = ((c_size + 1) / 2 + kPairsPerWave - 1) / kPairsPerWave;
+            uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
+            hipLaunchKernelGGL(block_mac_mfma_f16_kernel, dim3(grid), dim3(kThreads), 0, st, tasks_sorted, task_begin, A->bmps, A->offsets,
+                               (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
+                               (float *)C->values, c_size, a_bytes, b_bytes);
+        }
+        BMSP_CHECK_LAUNCH();
+        S->mac_kernel = tc_version;
+    } else {
+        if (A->dtype == BMSP_F32 && launch_mac_f32_mfma(tasks_sorted, n_tasks, task_begin, c_of_wave, A, B, C, st)) S->mac_variant = BMSP_MAC_F32MFMA;
+        else if (A->dtype == BMSP_F32) launch_mac_valu<float>(tasks_sorted, task_begin, A, B, C, st);
+        else if (A->dtype == BMSP_F16) launch_mac_valu<_Float16>(tasks_sorted, task_begin, A, B, C, st);
+        else launch_mac_valu<double>(tasks_sorted, task_begin, A, B, C, st);
+        S->mac_kernel = 5;
+    }
+}
+
 void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, int tc_version, int verbose, hipStream_t st,
             bmsp_spgemm_stats *stats, bool structure_only)
 {
@@ -1191,47 +1238,16 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
 
     // T_7: block multiply-accumulate
     if (structure_only) {
-        if (C->nnz) BMSP_HIP(hipMemsetAsync(C->values, 0, dtype_size(C->dtype) * (size_t)C->nnz, st));  // bmsp_spgemm_symbolic
-    } else if (c_size) {
-        if (mfma) {
-            if ((uint64_t)A->values_extent() * 2 + 16 >= (1ull << 32) || (uint64_t)B->values_extent() * 2 + 16 >= (1ull << 32))
-                fail(BMSP_ERR_LIMIT, "MFMA block-MAC addresses operand values through 4 GiB buffer descriptors; use tc_version 5");
-            // the group kernel's 12-byte value loads may run past the last stored value: arrays from this library's
-            // allocator carry that slack (runtime.h), borrowed arrays (bmsp_matrix_from_arrays, ownership 2) may not
-            const uint32_t a_bytes = (uint32_t)(A->values_extent() * 2), b_bytes = (uint32_t)(B->values_extent() * 2);
-            const bool old_mac = getenv("BMSP_MAC_OLD") != nullptr;  // experiment switch: the r1 16x16x16 group kernel
-            if (tc_version == 4 && !old_mac && mac_mfma32_supported(A, B)) {
-                // many tasks per C tile and most candidate pairs alive: the strip kernel (operand reuse; reads A, B, C, not the task list)
-                if (mac_strip_eligible(A, B, C.get(), total, n_tasks, st)) {
-                    launch_mac_strip(A, B, C.get(), st);
-                    S->mac_variant = BMSP_MAC_STRIP;
-                } else {
-                    S->mac_variant = launch_mac_mfma32(tasks_sorted, n_tasks, task_begin.p, c_of_wave.p, A, B, C.get(), st);
-                }
-            } else if (tc_version == 4 && pool_owns(A->values) && pool_owns(B->values) && A->block_num < (1ll << 28) && B->block_num < (1ll << 28)) {
-                ensure_block_meta(A, st);
-                ensure_block_meta(B, st);
-                uint32_t groups = (c_size + kGroupC - 1) / kGroupC;
-                uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
-                hipLaunchKernelGGL(block_mac_mfma_f16_group_kernel, dim3(grid), dim3(kThreads), 0, st, tasks_sorted, task_begin.p, A->block_meta,
-                                   (uint32_t)(A->block_num * 16), (const _Float16 *)A->values, B->block_meta, (uint32_t)(B->block_num * 16),
-                                   (const _Float16 *)B->values, C->bmps, C->offsets, (float *)C->values, c_size, a_bytes + 16u, b_bytes + 16u);
-            } else {
-                uint32_t groups = ((c_size + 1) / 2 + kPairsPerWave - 1) / kPairsPerWave;
-                uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)groups + 3) / 4, 256ull * 64);
-                hipLaunchKernelGGL(block_mac_mfma_f16_kernel, dim3(grid), dim3(kThreads), 0, st, tasks_sorted, task_begin.p, A->bmps, A->offsets,
-                                   (const _Float16 *)A->values, B->bmps, B->offsets, (const _Float16 *)B->values, C->bmps, C->offsets,
-                                   (float *)C->values, c_size, a_bytes, b_bytes);
-            }
-            BMSP_CHECK_LAUNCH();
-            S->mac_kernel = tc_version;
-        } else {
-            if (A->dtype == BMSP_F32 && launch_mac_f32_mfma(tasks_sorted, n_tasks, task_begin.p, c_of_wave.p, A, B, C.get(), st)) S->mac_variant = BMSP_MAC_F32MFMA;
-            else if (A->dtype == BMSP_F32) launch_mac_valu<float>(tasks_sorted, task_begin.p, A, B, C.get(), st);
-            else if (A->dtype == BMSP_F16) launch_mac_valu<_Float16>(tasks_sorted, task_begin.p, A, B, C.get(), st);
-            else launch_mac_valu<double>(tasks_sorted, task_begin.p, A, B, C.get(), st);
-            S->mac_kernel = 5;
+        // bmsp_spgemm_symbolic: zero values, and C keeps the sorted task list so that bmsp_spgemm_numeric can run T_7 alone from it
+        if (C->nnz) BMSP_HIP(hipMemsetAsync(C->values, 0, dtype_size(C->dtype) * (size_t)C->nnz, st));
+        if (c_size && n_tasks) {
+            C->sp_tasks = have_tasks ? rm_tasks.take() : (tasks_sorted == v0.p ? v0.take() : v1.take());
+            C->sp_task_begin = task_begin.take();
+            C->sp_c_of_wave = c_of_wave.take();
+            C->sp_n_tasks = n_tasks; C->sp_candidates = total; C->sp_a_blocks = A->block_num; C->sp_b_blocks = B->block_num;
         }
+    } else if (c_size) {
+        launch_block_mac(A, B, C.get(), tasks_sorted, n_tasks, task_begin.p, c_of_wave.p, total, tc_version, mfma, S, st);
     }
     tm.mark(7);
     finish();
@@ -1275,6 +1291,18 @@ void spgemm_numeric(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc
         S->t_us[0] = tm.collect(S->t_us);
         S->mac_variant = BMSP_MAC_STRIP;
         S->mac_kernel = mfma ? tc_version : 5;
+        S->c_blocks = C->block_num; S->c_nnz = C->nnz;
+        return;
+    }
+    if (C->block_num && C->sp_tasks && C->sp_a_blocks == A->block_num && C->sp_b_blocks == B->block_num) {
+        // C kept the product's sorted task list (bmsp_spgemm_symbolic): the block-MAC kernel of the tc_version runs from it
+        StageTimer tm(st, true);
+        tm.mark(-1);
+        launch_block_mac(A, B, C, C->sp_tasks, C->sp_n_tasks, C->sp_task_begin, C->sp_c_of_wave, C->sp_candidates, tc_version, mfma, S, st);
+        tm.mark(7);
+        BMSP_HIP(hipStreamSynchronize(st));
+        S->t_us[0] = tm.collect(S->t_us);
+        S->surviving_tasks = (int64_t)C->sp_n_tasks; S->task_list_size = (int64_t)C->sp_candidates;
         S->c_blocks = C->block_num; S->c_nnz = C->nnz;
         return;
     }

@@ -226,12 +226,14 @@ int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, in
 /* The two halves of bmsp_spgemm for callers that multiply the same sparsity pattern again and again (new values in A / B, same
  * structure: time stepping, AMG set-ups).  The reference has one entry point, bmSparse_mult, whose stages T_1 ... T_9 are the symbolic half
  * (src/bmSparse_SPGEMM.cu:849-1107: C's keys, bitmaps, offsets, nnz) and T_7 the numeric half (:1109-1158).
- *   bmsp_spgemm_symbolic: C's structure only; *C's values are allocated and zero.  Same arguments as bmsp_spgemm otherwise.
+ *   bmsp_spgemm_symbolic: C's structure only; *C's values are allocated and zero; where the product was formed through a task list, C
+ *                         keeps that list (8 bytes per surviving pair + 4 per C tile, freed with C).  Same arguments as bmsp_spgemm otherwise.
  *   bmsp_spgemm_numeric : C must hold the structure of A x B (from bmsp_spgemm / _symbolic on operands of the SAME structure); its values
  *                         are overwritten with those of A x B under tc_version's numerics -- exactly what bmsp_spgemm would store.  Where a
  *                         strip block-MAC applies (fp16 operands with tc_version 4, fp32 operands; block-rows of C of at most 256 tiles)
- *                         only that kernel runs; otherwise the whole product runs, its structure is checked against C's
- *                         (BMSP_ERR_INVALID on a mismatch) and its values are copied.  After changing an operand's values in place call
+ *                         only that kernel runs; a C from bmsp_spgemm_symbolic that kept its task list runs the tc_version's block-MAC
+ *                         kernel from it (any value type); otherwise (a C from bmsp_spgemm) the whole product runs, its structure is
+ *                         checked against C's (BMSP_ERR_INVALID on a mismatch) and its values are copied.  After changing an operand's values in place call
  *                         bmsp_matrix_invalidate(m, 0) first (cached tile copies). */
 int bmsp_spgemm_symbolic(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, void *stream,
                          bmsp_spgemm_stats *stats);

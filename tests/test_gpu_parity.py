@@ -840,6 +840,7 @@ def test_spgemm_symbolic_numeric_split(oracle, bmsp, case, dtype, tc):
     np.testing.assert_array_equal(sym.host_arrays()[3], vf)
     if (dtype == 0 or (dtype == 1 and tc == 4)) and case != "rmat_hub":
         assert stn["mac_variant"] == 3, stn  # the strip kernel alone
+    assert stn["t_us"][3] == 0 and stn["t_us"][4] == 0 and stn["t_us"][5] == 0 and stn["t_us"][7] > 0, stn  # no symbolic stage ran: T_7 from C's kept task list
     # new values, same structure
     A2 = A[:4] + (np.asarray(A[4]) * 0.5,)
     B2 = Bc[:4] + (np.asarray(Bc[4]) * -2.0,)
