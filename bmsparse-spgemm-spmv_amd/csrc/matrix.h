@@ -125,7 +125,7 @@ bool mac_strip_fits_c(bmsp_matrix_s *C, hipStream_t st);
 uint32_t mac_strip_row_cap();
 void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);
 bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, uint32_t row_cap,
-                       uint64_t *surviving, hipStream_t st);
+                       uint64_t *surviving, uint64_t *candidates, hipStream_t st);
 bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, DevBuf<uint64_t> &tasks,
                        DevBuf<uint32_t> &task_begin, DevBuf<uint32_t> &c_of_wave, uint64_t *n_tasks, hipStream_t st);
 void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st);

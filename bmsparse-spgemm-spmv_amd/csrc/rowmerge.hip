@@ -29,7 +29,8 @@ struct RowMergeArgs {
     const uint32_t *b_rowptr;
     uint32_t block_rows, b_block_rows;
     uint32_t row_cap;         // distinct C tiles per block-row the caller accepts (<= kRowCap)
-    const uint32_t *tmp_off;  // block_rows + 1: first scratch slot of block-row i
+    const uint32_t *tmp_off;  // block_rows + 1: first scratch slot of block-row i; null: row_cap slots per block-row
+    uint32_t *cand;           // when tmp_off is null (T_2 did not run): candidate pairs of block-row i
     uint32_t *t_cols;         // scratch: C's block columns of row i, ascending
     uint64_t *t_bmps;         //          and their bitmaps
     uint32_t *cnt;            // block_rows (+ 1, the scan reads one past): C tiles of row i
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
     const uint32_t a0 = g.a_rowptr[row], a1 = g.a_rowptr[row + 1];
     // (a block-row beyond the cap makes the whole pass void: the waves that start after it was seen leave at once)
     if (a0 == a1 || __builtin_nontemporal_load(g.overflow) != 0u) {
-        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; g.nnz[row] = 0u; }
+        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; g.nnz[row] = 0u; if (g.cand) g.cand[row] = 0u; }
         return;
     }
     for (uint32_t s = (uint32_t)lane; s < (uint32_t)kHash; s += 64) { S.hk[s] = kEmpty; S.hb[s] = 0ull; }
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
         return true;
     });
     if (!done || n > g.row_cap) {
-        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; g.nnz[row] = 0u; atomicOr(g.overflow, 1u); }
+        if (lane == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; g.nnz[row] = 0u; if (g.cand) g.cand[row] = 0u; atomicOr(g.overflow, 1u); }
         return;
     }
     __builtin_amdgcn_wave_barrier();
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
     if (lane < 4) S.hk[m + (uint32_t)lane] = kEmpty;
     __builtin_amdgcn_wave_barrier();
     // rank by column: n is small (a block-row of C), every lane counts the keys below its own; the reads are wave-wide broadcasts
-    const uint32_t out0 = g.tmp_off[row];
+    const uint32_t out0 = g.tmp_off ? g.tmp_off[row] : row * g.row_cap;
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
     uint32_t nz = 0;
     for (uint32_t p0 = 0; p0 < m; p0 += 64) {
@@ -262,6 +263,15 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
     }
     surv = wave_sum(surv);
     nz = wave_sum(nz);
+    if (g.cand) {  // the block-row's candidate pairs ("Task list size" without T_2's scan)
+        uint32_t cd = 0;
+        for (uint32_t a = a0 + (uint32_t)lane; a < a1; a += 64) {
+            const uint32_t k = key_col(g.a_keys[a]);
+            if (k < g.b_block_rows) cd += g.b_rowptr[k + 1] - g.b_rowptr[k];
+        }
+        cd = wave_sum(cd);
+        if (lane == 0) g.cand[row] = cd;
+    }
     if (lane == 0) { g.cnt[row] = m; g.surv[row] = surv; g.nnz[row] = nz; }  // (per-row results: one atomic pair per wave would serialise at the memory side)
 }
 
@@ -508,23 +518,24 @@ struct CntSurvIn {
 struct PublishStats {
     const unsigned long long *acc;  // [0] surviving pairs, [1] most C tiles in a block-row
     const uint32_t *overflow;
-    uint64_t *h_surviving, *h_max_over;
+    uint64_t *h_surviving, *h_max_over, *h_cand;
     __device__ void operator()(uint64_t) const
     {
         *h_surviving = (uint64_t)acc[0];
         *h_max_over = ((uint64_t)*overflow << 32) | (uint64_t)acc[1];
+        *h_cand = (uint64_t)acc[3];
     }
 };
 
 // scratch -> C's own arrays: one wave per block-row
 __global__ __launch_bounds__(kThreads) void rowmerge_emit_kernel(const uint32_t *__restrict__ tmp_off, const uint32_t *__restrict__ t_cols,
                                                                   const uint64_t *__restrict__ t_bmps, const uint32_t *__restrict__ c_rowptr,
-                                                                  const uint64_t *__restrict__ row_val0, uint32_t block_rows,
+                                                                  const uint64_t *__restrict__ row_val0, uint32_t block_rows, uint32_t stride,
                                                                   uint64_t *__restrict__ c_keys, uint64_t *__restrict__ c_bmps, uint64_t *__restrict__ c_offs)
 {
     const uint32_t row = blockIdx.x * 4 + (uint32_t)wave_id();
     if (row >= block_rows) return;
-    const uint32_t c0 = c_rowptr[row], n = c_rowptr[row + 1] - c0, t0 = tmp_off[row];
+    const uint32_t c0 = c_rowptr[row], n = c_rowptr[row + 1] - c0, t0 = tmp_off ? tmp_off[row] : row * stride;
     for (uint32_t p = (uint32_t)lane_id(); p < n; p += 64) {
         c_keys[c0 + p] = key_make(row, t_cols[t0 + p]);
         c_bmps[c0 + p] = t_bmps[t0 + p];
@@ -550,32 +561,35 @@ struct SetU64 {
 // (nothing of C was allocated; the caller runs the pipeline).  true: C->keys / bmps / offsets / nnz / rowptr / block_num / max_row_blocks
 // are set (the value array is the caller's to allocate), *surviving = candidate pairs that passed the bitmap filter.
 bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, uint32_t row_cap,
-                       uint64_t *surviving, hipStream_t st)
+                       uint64_t *surviving, uint64_t *candidates, hipStream_t st)
 {
+    // first_pos == nullptr: T_2 did not run (a pair of operands known to fit this pass): every block-row gets row_cap scratch slots and the
+    // pass counts the candidate pairs itself (*candidates)
     row_cap = std::min(row_cap, kRowCap);
     const uint64_t rows = (uint64_t)A->num_block_rows();
-    if (rows == 0 || rows >= (1ull << 31) || total == 0 || total >= (1ull << 32)) return false;
+    if (rows == 0 || rows >= (1ull << 31)) return false;
+    if (first_pos && (total == 0 || total >= (1ull << 32))) return false;
     ensure_rowptr(A, st);
     ensure_rowptr(B, st);
-    const uint64_t slots = std::min<uint64_t>(total, rows * (uint64_t)row_cap);
+    const uint64_t slots = first_pos ? std::min<uint64_t>(total, rows * (uint64_t)row_cap) : rows * (uint64_t)row_cap;
     if (slots >= (1ull << 31)) return false;
-    DevBuf<uint32_t> tmp_off(rows + 1), cnt(rows + 1), surv_row(rows), nnz_row(rows + 1), t_cols(slots);
+    DevBuf<uint32_t> tmp_off(first_pos ? rows + 1 : 1), cnt(rows + 1), surv_row(rows), nnz_row(rows + 1), cand_row(first_pos ? 1 : rows), t_cols(slots);
     DevBuf<uint64_t> row_val0(rows + 1);
     DevBuf<uint64_t> t_bmps(slots);
-    DevBuf<unsigned long long> acc(3);  // [0] surviving pairs, [1] most C tiles in a block-row, [2] overflow flag
-    BMSP_HIP(hipMemsetAsync(acc.p, 0, 24, st));
-    device_exclusive_scan<uint32_t>(RowSlotsIn{first_pos, A->rowptr, rows, row_cap}, PtrOut<uint32_t>{tmp_off.p}, rows + 1, st);
+    DevBuf<unsigned long long> acc(4);  // [0] surviving pairs, [1] most C tiles in a block-row, [2] overflow flag, [3] candidate pairs
+    BMSP_HIP(hipMemsetAsync(acc.p, 0, 32, st));
+    if (first_pos) device_exclusive_scan<uint32_t>(RowSlotsIn{first_pos, A->rowptr, rows, row_cap}, PtrOut<uint32_t>{tmp_off.p}, rows + 1, st);
     RowMergeArgs g{};
     g.a_keys = A->keys; g.a_bmps = A->bmps; g.a_rowptr = A->rowptr;
     g.b_keys = B->keys; g.b_bmps = B->bmps; g.b_rowptr = B->rowptr;
     g.block_rows = (uint32_t)rows; g.b_block_rows = (uint32_t)B->num_block_rows(); g.row_cap = row_cap;
-    g.tmp_off = tmp_off.p; g.t_cols = t_cols.p; g.t_bmps = t_bmps.p; g.cnt = cnt.p;
+    g.tmp_off = first_pos ? tmp_off.p : nullptr; g.cand = first_pos ? nullptr : cand_row.p; g.t_cols = t_cols.p; g.t_bmps = t_bmps.p; g.cnt = cnt.p;
     g.surv = surv_row.p; g.nnz = nnz_row.p; g.overflow = (uint32_t *)(acc.p + 2);
     hipLaunchKernelGGL(rowmerge_symbolic_kernel<1>, dim3((uint32_t)((rows + 3) / 4)), dim3(kThreads), 0, st, g);
     BMSP_CHECK_LAUNCH();
     uint32_t *c_rowptr = (uint32_t *)pool_alloc(sizeof(uint32_t) * (size_t)(rows + 1));
     HostScalar<uint32_t> c_size_h;
-    HostScalar<uint64_t> surv_h, mo_h, nnz_h;
+    HostScalar<uint64_t> surv_h, mo_h, nnz_h, cand_h;
     uint32_t c_size = 0;
     uint64_t mo = 0, c_nnz = 0;
     try {
@@ -583,11 +597,13 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
         device_exclusive_scan<uint64_t>(Cnt64In{nnz_row.p, rows}, PtrOutTotal<uint64_t>{row_val0.p, rows, nnz_h.dev()}, rows + 1, st);
         device_max_sum(CntSurvIn{surv_row.p}, rows, (unsigned long long *)nullptr, acc.p, st);
         device_max_sum(CntSurvIn{cnt.p}, rows, acc.p + 1, (unsigned long long *)nullptr, st);
-        device_for_each(PublishStats{acc.p, g.overflow, surv_h.dev(), mo_h.dev()}, 1, st);
+        if (!first_pos) device_max_sum(CntSurvIn{cand_row.p}, rows, (unsigned long long *)nullptr, acc.p + 3, st);
+        device_for_each(PublishStats{acc.p, g.overflow, surv_h.dev(), mo_h.dev(), cand_h.dev()}, 1, st);
         c_size = c_size_h.wait(st);
         c_nnz = nnz_h.wait(st);
         *surviving = surv_h.wait(st);
         mo = mo_h.wait(st);
+        *candidates = first_pos ? total : cand_h.wait(st);
     } catch (...) {
         pool_free(c_rowptr);
         throw;
@@ -606,8 +622,8 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     C->nnz = (int64_t)c_nnz;
     device_for_each(SetU64{C->offsets + c_size, c_nnz}, 1, st);
     if (c_size) {
-        hipLaunchKernelGGL(rowmerge_emit_kernel, dim3((uint32_t)((rows + 3) / 4)), dim3(kThreads), 0, st, tmp_off.p, t_cols.p, t_bmps.p, c_rowptr, row_val0.p,
-                           (uint32_t)rows, C->keys, C->bmps, C->offsets);
+        hipLaunchKernelGGL(rowmerge_emit_kernel, dim3((uint32_t)((rows + 3) / 4)), dim3(kThreads), 0, st, first_pos ? tmp_off.p : (const uint32_t *)nullptr, t_cols.p,
+                           t_bmps.p, c_rowptr, row_val0.p, (uint32_t)rows, row_cap, C->keys, C->bmps, C->offsets);
         BMSP_CHECK_LAUNCH();
     }
     return true;

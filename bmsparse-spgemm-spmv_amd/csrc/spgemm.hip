@@ -988,15 +988,19 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
 
     // T_2 + T_3 (first half): fan-out per A block and its exclusive scan
     const uint64_t n_a = (uint64_t)A->block_num;
-    DevBuf<uint64_t> first_pos(n_a + 1);
-    HostScalar<uint64_t> total_h;
-    device_exclusive_scan<uint64_t>(FanOut{A->keys, B->rowptr, n_a, (uint32_t)B->num_block_rows()}, PtrOutTotal<uint64_t>{first_pos.p, n_a, total_h.dev()},
-                                    n_a + 1, st);
-    const uint64_t total = total_h.wait(st);
-    tm.mark(2);
-    S->task_list_size = (int64_t)total;
-    if (total >= (1ull << 32))  // bmsp_spgemm retries in block-row panels (shard.hip: spgemm_paneled)
-        throw TaskRangeExceeded(BMSP_ERR_LIMIT, std::to_string(total) + " candidate block pairs exceed the 32-bit range of one task list");
+    DevBuf<uint64_t> first_pos;
+    uint64_t total = 0;
+    auto run_t2 = [&]() {
+        first_pos.alloc(n_a + 1);
+        HostScalar<uint64_t> total_h;
+        device_exclusive_scan<uint64_t>(FanOut{A->keys, B->rowptr, n_a, (uint32_t)B->num_block_rows()}, PtrOutTotal<uint64_t>{first_pos.p, n_a, total_h.dev()},
+                                        n_a + 1, st);
+        total = total_h.wait(st);
+        tm.mark(2);
+        S->task_list_size = (int64_t)total;
+        if (total >= (1ull << 32))  // bmsp_spgemm retries in block-row panels (shard.hip: spgemm_paneled)
+            throw TaskRangeExceeded(BMSP_ERR_LIMIT, std::to_string(total) + " candidate block pairs exceed the 32-bit range of one task list");
+    };
 
     std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> C(new bmsp_matrix_s(), free_matrix);
     C->num_rows = A->num_rows; C->num_cols = B->num_cols;  // :1171-1172
@@ -1062,43 +1066,67 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     {
         const char *rme = getenv("BMSP_SPGEMM_ROWMERGE");
         const bool rm_force = rme && rme[0] != '0', rm_off = rme && rme[0] == '0', rm_no_strip = rme && rme[0] == '2';
-        const bool rm_on = !rm_off && total && (mode == BMSP_SORT_AUTO || rm_force);
         const bool known = A->rm_partner_keys == (const void *)B->keys && A->rm_partner_blocks == B->block_num;
         const int hint = known ? A->rm_partner_mode : 0;  // 0 unknown, 1 strip mode fits, 2 task-list mode, 3 pipeline
         auto remember = [&](int m) { A->rm_partner_keys = B->keys; A->rm_partner_blocks = B->block_num; A->rm_partner_mode = m; };
         // numeric stages that work from C's structure alone: the K = 32 MFMA strip kernel (tc_version 4, fp16) and its fp32 form (V15's
         // summation order on v_mfma_f32_16x16x4_f32: any tc_version, as fp32 operands always take V15's numerics)
         const bool rm_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || (A->dtype == BMSP_F32 && !getenv("BMSP_MAC_VALU_DENSE") && !getenv("BMSP_MAC_F32MFMA"));
-        bool try_strip = rm_on && rm_numeric && !rm_no_strip && hint != 2 && hint != 3;
-        if (try_strip) {
-            const char *sf = getenv("BMSP_MAC_STRIP");
-            try_strip = !(sf && sf[0] == '0') && mac_strip_operands_ok(A, B, st);
-        }
-        if (try_strip) {
+        const char *sf = getenv("BMSP_MAC_STRIP");
+        const bool strip_allowed = rm_numeric && !rm_no_strip && !(sf && sf[0] == '0');
+        // strip mode done: value array, numeric stage (or zero values for bmsp_spgemm_symbolic), statistics
+        auto finish_strip = [&](uint64_t surv) {
+            tm.mark(3);
+            remember(1);
+            S->task_list_size = (int64_t)total;
+            S->surviving_tasks = (int64_t)surv;
+            S->bmp_reduction = (int64_t)(total - surv);
+            S->sort_path = BMSP_SORT_PATH_ROWMERGE;
+            finish_structure();
+            tm.mark(9);
+            if (C->block_num && !structure_only) {
+                launch_mac_strip(A, B, C.get(), st);
+                S->mac_variant = BMSP_MAC_STRIP;
+                S->mac_kernel = mfma ? tc_version : 5;
+            } else if (C->nnz) {
+                BMSP_HIP(hipMemsetAsync(C->values, 0, dtype_size(C->dtype) * (size_t)C->nnz, st));  // bmsp_spgemm_symbolic: structure only
+            }
+            tm.mark(7);
+            finish();
+        };
+        auto drop_structure = [&]() {
+            pool_free(C->keys); pool_free(C->bmps); pool_free(C->rowptr); pool_free(C->offsets);
+            C->keys = nullptr; C->bmps = nullptr; C->rowptr = nullptr; C->offsets = nullptr; C->nnz = 0;
+            C->rowptr_rows = 0; C->max_row_blocks = -1; C->block_num = 0;
+        };
+        bool strip_tried = false;
+        // A pair of operands known to fit strip mode: the pass runs WITHOUT T_2 (its scan, and the wait for its total, only serve the task
+        // list); it counts the candidate pairs itself.
+        if (known && hint == 1 && n_a && strip_allowed && (mode == BMSP_SORT_AUTO || rm_force) && !rm_off && mac_strip_operands_ok(A, B, st)) {
             uint64_t surv = 0;
-            if (rowmerge_symbolic(A, B, C.get(), first_pos.p, total, mac_strip_row_cap(), &surv, st)) {
+            strip_tried = true;
+            if (rowmerge_symbolic(A, B, C.get(), nullptr, 0, mac_strip_row_cap(), &surv, &total, st)) {
                 if (C->block_num == 0 || mac_strip_fits_c(C.get(), st)) {
-                    tm.mark(3);
-                    remember(1);
-                    S->surviving_tasks = (int64_t)surv;
-                    S->bmp_reduction = (int64_t)(total - surv);
-                    S->sort_path = BMSP_SORT_PATH_ROWMERGE;
-                    finish_structure();
-                    tm.mark(9);
-                    if (C->block_num && !structure_only) {
-                        launch_mac_strip(A, B, C.get(), st);
-                        S->mac_variant = BMSP_MAC_STRIP;
-                        S->mac_kernel = mfma ? tc_version : 5;
-                    } else if (C->nnz) {
-                        BMSP_HIP(hipMemsetAsync(C->values, 0, dtype_size(C->dtype) * (size_t)C->nnz, st));  // bmsp_spgemm_symbolic: structure only
-                    }
-                    tm.mark(7);
-                    finish();
+                    finish_strip(surv);
+                    return;
+                }
+                drop_structure();
+            }
+            tm.mark(-1);
+        }
+        run_t2();
+        const bool rm_on = !rm_off && total && (mode == BMSP_SORT_AUTO || rm_force);
+        bool try_strip = rm_on && strip_allowed && !strip_tried && hint != 2 && hint != 3;
+        if (try_strip) try_strip = mac_strip_operands_ok(A, B, st);
+        if (try_strip) {
+            uint64_t surv = 0, cand = 0;
+            if (rowmerge_symbolic(A, B, C.get(), first_pos.p, total, mac_strip_row_cap(), &surv, &cand, st)) {
+                if (C->block_num == 0 || mac_strip_fits_c(C.get(), st)) {
+                    finish_strip(surv);
                     return;
                 }
                 // C exists but a strip of it exceeds the kernel's column list: drop it
-                pool_free(C->keys); pool_free(C->bmps); pool_free(C->rowptr); pool_free(C->offsets);
-                C->keys = nullptr; C->bmps = nullptr; C->rowptr = nullptr; C->offsets = nullptr; C->nnz = 0; C->rowptr_rows = 0; C->max_row_blocks = -1; C->block_num = 0;
+                drop_structure();
             }
             tm.mark(-1);
         }
