@@ -515,6 +515,35 @@ struct CntSurvIn {
     const uint32_t *p;
     __device__ uint64_t operator()(uint64_t i) const { return (uint64_t)p[i]; }
 };
+// most C tiles in a block-row, surviving pairs and (when counted by the pass) candidate pairs of the whole product: one launch, one atomic
+// per figure and workgroup
+__global__ __launch_bounds__(kThreads) void rows_stats_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ surv, const uint32_t *__restrict__ cand,
+                                                               uint32_t rows, unsigned long long *acc)
+{
+    __shared__ unsigned long long l[3][4];
+    unsigned long long mx = 0, ss = 0, sc = 0;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < rows; i += gridDim.x * kThreads) {
+        const unsigned long long c = cnt[i];
+        mx = c > mx ? c : mx;
+        ss += surv[i];
+        if (cand) sc += cand[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(mx, d, kWave);
+        mx = o > mx ? o : mx;
+    }
+    ss = wave_sum(ss); sc = wave_sum(sc);
+    if (lane_id() == 0) { l[0][wave_id()] = mx; l[1][wave_id()] = ss; l[2][wave_id()] = sc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { mx = l[0][w] > mx ? l[0][w] : mx; ss += l[1][w]; sc += l[2][w]; }
+        atomicAdd(acc + 0, ss);
+        atomicMax(acc + 1, mx);
+        if (cand) atomicAdd(acc + 3, sc);
+    }
+}
+
 struct PublishStats {
     const unsigned long long *acc;  // [0] surviving pairs, [1] most C tiles in a block-row
     const uint32_t *overflow;
@@ -595,9 +624,9 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     try {
         device_exclusive_scan<uint32_t>(CntIn{cnt.p, rows}, PtrOutTotal<uint32_t>{c_rowptr, rows, c_size_h.dev()}, rows + 1, st);
         device_exclusive_scan<uint64_t>(Cnt64In{nnz_row.p, rows}, PtrOutTotal<uint64_t>{row_val0.p, rows, nnz_h.dev()}, rows + 1, st);
-        device_max_sum(CntSurvIn{surv_row.p}, rows, (unsigned long long *)nullptr, acc.p, st);
-        device_max_sum(CntSurvIn{cnt.p}, rows, acc.p + 1, (unsigned long long *)nullptr, st);
-        if (!first_pos) device_max_sum(CntSurvIn{cand_row.p}, rows, (unsigned long long *)nullptr, acc.p + 3, st);
+        hipLaunchKernelGGL(rows_stats_kernel, dim3((uint32_t)std::min<uint64_t>((rows + kThreads - 1) / kThreads, 256)), dim3(kThreads), 0, st, cnt.p, surv_row.p,
+                           first_pos ? (const uint32_t *)nullptr : cand_row.p, (uint32_t)rows, acc.p);
+        BMSP_CHECK_LAUNCH();
         device_for_each(PublishStats{acc.p, g.overflow, surv_h.dev(), mo_h.dev(), cand_h.dev()}, 1, st);
         c_size = c_size_h.wait(st);
         c_nnz = nnz_h.wait(st);
