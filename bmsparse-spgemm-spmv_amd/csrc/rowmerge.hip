@@ -515,6 +515,26 @@ struct CntSurvIn {
     const uint32_t *p;
     __device__ uint64_t operator()(uint64_t i) const { return (uint64_t)p[i]; }
 };
+// C tiles and values per block-row scanned together: (tiles << 33) | values in one 64-bit scan (fewer than 2^27 tiles: values < 2^33)
+struct CntNnzIn {
+    const uint32_t *cnt, *nnz;
+    uint64_t rows;
+    __device__ uint64_t operator()(uint64_t i) const { return i < rows ? ((uint64_t)cnt[i] << 33) | (uint64_t)nnz[i] : 0ull; }
+};
+struct CntNnzOut {
+    uint32_t *c_rowptr;
+    uint64_t *row_val0;
+    uint64_t rows;
+    uint32_t *h_c_size;
+    uint64_t *h_nnz;
+    __device__ void operator()(uint64_t i, uint64_t ex) const
+    {
+        c_rowptr[i] = (uint32_t)(ex >> 33);
+        row_val0[i] = ex & ((1ull << 33) - 1ull);
+        if (i == rows) { *h_nnz = ex & ((1ull << 33) - 1ull); *h_c_size = (uint32_t)(ex >> 33); }
+    }
+};
+
 // most C tiles in a block-row, surviving pairs and (when counted by the pass) candidate pairs of the whole product: one launch, one atomic
 // per figure and workgroup
 __global__ __launch_bounds__(kThreads) void rows_stats_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ surv, const uint32_t *__restrict__ cand,
@@ -622,8 +642,12 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     uint32_t c_size = 0;
     uint64_t mo = 0, c_nnz = 0;
     try {
-        device_exclusive_scan<uint32_t>(CntIn{cnt.p, rows}, PtrOutTotal<uint32_t>{c_rowptr, rows, c_size_h.dev()}, rows + 1, st);
-        device_exclusive_scan<uint64_t>(Cnt64In{nnz_row.p, rows}, PtrOutTotal<uint64_t>{row_val0.p, rows, nnz_h.dev()}, rows + 1, st);
+        if (slots < (1ull << 27)) {
+            device_exclusive_scan<uint64_t>(CntNnzIn{cnt.p, nnz_row.p, rows}, CntNnzOut{c_rowptr, row_val0.p, rows, c_size_h.dev(), nnz_h.dev()}, rows + 1, st);
+        } else {
+            device_exclusive_scan<uint32_t>(CntIn{cnt.p, rows}, PtrOutTotal<uint32_t>{c_rowptr, rows, c_size_h.dev()}, rows + 1, st);
+            device_exclusive_scan<uint64_t>(Cnt64In{nnz_row.p, rows}, PtrOutTotal<uint64_t>{row_val0.p, rows, nnz_h.dev()}, rows + 1, st);
+        }
         hipLaunchKernelGGL(rows_stats_kernel, dim3((uint32_t)std::min<uint64_t>((rows + kThreads - 1) / kThreads, 256)), dim3(kThreads), 0, st, cnt.p, surv_row.p,
                            first_pos ? (const uint32_t *)nullptr : cand_row.p, (uint32_t)rows, acc.p);
         BMSP_CHECK_LAUNCH();
