@@ -730,9 +730,13 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     uint32_t c_size = 0, n_tasks = 0;
     uint64_t mo = 0, c_nnz = 0;
     try {
-        device_exclusive_scan<uint32_t>(CntIn{cnt.p, rows}, PtrOutTotal<uint32_t>{c_rowptr, rows, c_size_h.dev()}, rows + 1, st);
+        if (total < (1ull << 27)) {  // (C tiles <= surviving pairs <= candidate pairs)
+            device_exclusive_scan<uint64_t>(CntNnzIn{cnt.p, nnz_row.p, rows}, CntNnzOut{c_rowptr, row_val0.p, rows, c_size_h.dev(), nnz_h.dev()}, rows + 1, st);
+        } else {
+            device_exclusive_scan<uint32_t>(CntIn{cnt.p, rows}, PtrOutTotal<uint32_t>{c_rowptr, rows, c_size_h.dev()}, rows + 1, st);
+            device_exclusive_scan<uint64_t>(Cnt64In{nnz_row.p, rows}, PtrOutTotal<uint64_t>{row_val0.p, rows, nnz_h.dev()}, rows + 1, st);
+        }
         device_exclusive_scan<uint32_t>(CntIn{surv_row.p, rows}, PtrOutTotal<uint32_t>{row_task0.p, rows, n_tasks_h.dev()}, rows + 1, st);
-        device_exclusive_scan<uint64_t>(Cnt64In{nnz_row.p, rows}, PtrOutTotal<uint64_t>{row_val0.p, rows, nnz_h.dev()}, rows + 1, st);
         device_max_sum(CntSurvIn{cnt.p}, rows, acc.p + 1, (unsigned long long *)nullptr, st);
         device_for_each(PublishTaskStats{acc.p, mo_h.dev()}, 1, st);
         c_size = c_size_h.wait(st);
