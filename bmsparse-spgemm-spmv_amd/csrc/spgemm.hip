@@ -1102,7 +1102,11 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         bool strip_tried = false;
         // A pair of operands known to fit strip mode: the pass runs WITHOUT T_2 (its scan, and the wait for its total, only serve the task
         // list); it counts the candidate pairs itself.
-        if (known && hint == 1 && n_a && strip_allowed && (mode == BMSP_SORT_AUTO || rm_force) && !rm_off && mac_strip_operands_ok(A, B, st)) {
+        // (also for a pair never seen whose row maxima bound every block-row of C by the strip kernel's capacity)
+        const bool surely_fits = A->max_row_blocks >= 0 && B->max_row_blocks >= 0 &&
+                                 (uint64_t)A->max_row_blocks * (uint64_t)B->max_row_blocks <= (uint64_t)mac_strip_row_cap();
+        if (((known && hint == 1) || (hint == 0 && surely_fits)) && n_a && strip_allowed && (mode == BMSP_SORT_AUTO || rm_force) && !rm_off &&
+            mac_strip_operands_ok(A, B, st)) {
             uint64_t surv = 0;
             strip_tried = true;
             if (rowmerge_symbolic(A, B, C.get(), nullptr, 0, mac_strip_row_cap(), &surv, &total, st)) {
