@@ -9,7 +9,9 @@
 // compacted, ranked by column (C's key order inside the row) and written once.  Same keys, same bitmaps, same value offsets as the
 // pipeline's; the numeric stage that follows (blockmac_strip.hip) recomputes which tiles meet from the operands, as it always did.
 //
-// Limits (the caller keeps the expand-sort-compress pipeline otherwise): at most kRowCap distinct C tiles per block-row.
+// Two forms: the strip-mode pass below (structure only: block-rows of C of at most 256 tiles, numeric stage by the strip kernels) and the
+// task-list form further down (build + copy passes: block-rows of up to ~900 tiles, the sorted task list for the task-list kernels).
+// Beyond those limits the caller keeps the expand-sort-compress pipeline.
 #include "matrix.h"
 #include "prims.hip.h"
 #include "bmsp_bits.h"
@@ -159,15 +161,6 @@ __device__ __forceinline__ uint32_t hash_insert(uint32_t *hk, uint32_t j, bool &
         slot = (slot + 1u) & ((1u << BITS) - 1u);
     }
 }
-// the slot of a column that is in the table
-template <int BITS>
-__device__ __forceinline__ uint32_t hash_find(const uint32_t *hk, uint32_t j)
-{
-    uint32_t slot = (j * 0x9E3779B1u) >> (32 - BITS);
-    while (hk[slot] != j) slot = (slot + 1u) & ((1u << BITS) - 1u);
-    return slot;
-}
-
 __device__ __forceinline__ uint32_t xcd_order(uint32_t b, uint32_t G)
 {  // the workgroups of one XCD take a contiguous eighth of the block-rows (neighbouring rows read the same block-rows of B)
     const uint32_t q = G / 8, rm = G % 8, x = b % 8;
