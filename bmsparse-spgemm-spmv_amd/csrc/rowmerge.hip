@@ -612,7 +612,9 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     if (rows == 0 || rows >= (1ull << 31)) return false;
     if (first_pos && (total == 0 || total >= (1ull << 32))) return false;
     ensure_rowptr(A, st);
-    ensure_rowptr(B, st);
+    ensure_row_stats(B, st);
+    // (a block-row of C holds at least the tiles of the longest block-row of B it meets: operands with a hub block-row are not tried)
+    if (B->max_row_blocks > (int64_t)row_cap) return false;
     const uint64_t slots = first_pos ? std::min<uint64_t>(total, rows * (uint64_t)row_cap) : rows * (uint64_t)row_cap;
     if (slots >= (1ull << 31)) return false;
     DevBuf<uint32_t> tmp_off(first_pos ? rows + 1 : 1), cnt(rows + 1), surv_row(rows), nnz_row(rows + 1), cand_row(first_pos ? 1 : rows), t_cols(slots);
@@ -700,7 +702,10 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     if (rows == 0 || rows >= (1ull << 31) || total == 0 || total >= (1ull << 32)) return false;
     if (total * 42 > (16ull << 30)) return false;  // scratch: 42 bytes per candidate pair
     ensure_rowptr(A, st);
-    ensure_rowptr(B, st);
+    ensure_row_stats(B, st);
+    // (a block-row of C holds at least the tiles of the longest block-row of B it meets: operands with a hub block-row -- power-law graphs --
+    // go to the pipeline without a pass being tried, and without its scratch being allocated)
+    if (B->max_row_blocks > (int64_t)(kTlCap + 63)) return false;
     DevBuf<uint32_t> cnt(rows + 1), surv_row(rows + 1), nnz_row(rows + 1), row_task0(rows + 1), s_cols(total), s_begin(total);
     DevBuf<uint64_t> row_val0(rows + 1);
     DevBuf<uint64_t> s_surv(total), s_prod(total), s_tasks(total), s_bmps(total);
