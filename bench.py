@@ -266,8 +266,9 @@ def main():
     for i in range(args.steps):
         S.step(i, variant)
     e1.record()
-    sync(); barrier()
-    wall = time.perf_counter() - t0
+    sync()
+    wall = time.perf_counter() - t0  # this rank's K steps, from the common start (barrier + synchronise above) to its own completion ...
+    barrier()                        # ... the closing barrier; the MAX over ranks below is the time at which the last rank was done
     dev_ms = e0.elapsed_ms(e1)
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
