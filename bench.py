@@ -34,7 +34,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA spec
 FP32_PEAK_TFLOPS = 157.3
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -52,7 +52,55 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="bound on the CPU-baseline work, all legs together")
     ap.add_argument("--vendor-timeout", type=float, default=150.0, help="the rocSPARSE column runs in a child process; on a fresh box paging librocsparse in can take minutes")
     ap.add_argument("--vendor-child", action="store_true", help=argparse.SUPPRESS)
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the child launcher started by --gpus N > 1 (0: a free one)")
+    return ap.parse_args(argv)
+
+
+def launcher_command(gpus, argv, port):
+    """the command `--gpus N` (N > 1, no WORLD_SIZE in the environment) starts: the driver's own form, one rank per GPU over RCCL"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if not a.startswith("--master-port")]
+
+
+def check_child_line(stdout_text, gpus):
+    """(line, error): rank 0's JSON line out of a child's stdout; an error when there is none, when it reports another number of GPUs
+    than asked for, or when RCCL saw fewer ranks"""
+    lines = [l for l in stdout_text.splitlines() if l.startswith("{")]
+    if not lines:
+        return None, "the %d-rank child printed no JSON line" % gpus
+    try:
+        d = json.loads(lines[-1])
+    except ValueError as e:
+        return None, "unparsable line from the child: %s" % e
+    if d.get("n_gpus") != gpus:
+        return lines[-1], "asked for --gpus %d but the line reports n_gpus = %r" % (gpus, d.get("n_gpus"))
+    if d.get("rccl_ranks") != gpus:
+        return lines[-1], "asked for --gpus %d but the RCCL communicator had %r ranks" % (gpus, d.get("rccl_ranks"))
+    return lines[-1], None
+
+
+def launch_ranks(args, argv, cmd=None):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: start the N ranks as a CHILD process -- before this process has made
+    any GPU call (an exec from a process that has touched the GPU is not allowed on this pool, and this one never touches it) -- relay
+    rank 0's line, and fail loudly when the line is not an N-GPU line.  The reference's analogue is "the driver runs the executable"
+    (spgemm_run_batch.sh:15)."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd or launcher_command(args.gpus, argv, port), stdout=subprocess.PIPE, text=True, env=env)
+    line, err = check_child_line(r.stdout, args.gpus)
+    if line:
+        print(line, flush=True)
+    if err or r.returncode:
+        print("[bench] --gpus %d: %s" % (args.gpus, err or "child exit code %d" % r.returncode), file=sys.stderr, flush=True)
+        return r.returncode or 3
+    return 0
 
 
 def csr_bytes(rows, nnz):
@@ -207,11 +255,19 @@ def main():
     args = parse()
     if args.vendor_child:
         return vendor_child(args)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("BMSP_FORCE_LAUNCH") == "1"):
+        # (BMSP_FORCE_LAUNCH=1 --gpus 1 rehearses the launcher with one rank on a one-GPU box)
+        os.environ["BMSP_FORCE_DIST"] = "1"
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("[bench] --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world), file=sys.stderr, flush=True)
+        sys.exit(3)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    rccl_ranks = None
     use_dist = world > 1 or os.environ.get("BMSP_FORCE_DIST") == "1"  # the latter rehearses the N>1 plumbing with one rank
     if use_dist:
         import torch  # before the bmsp library: one HIP runtime for both (see pybmsp docstring)
@@ -226,6 +282,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
+            ones = torch.ones(1, dtype=torch.int32, device="cuda")
+            dist.all_reduce(ones)  # counted over the wire: the ranks the RCCL communicator actually holds
+            rccl_ranks = int(ones.item()) if dist.get_backend() == "nccl" else 0
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
@@ -300,7 +359,7 @@ def main():
                 "avg_launch_ms": round(kern_ms, 5)}
 
     out = {"metric": "bmSparse SpMV fp32 effective GB/s (CSR-convention bytes / time); SpGEMM GFLOP/s under `spgemm`",
-           "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic" if "coo" in wl else "suitesparse",
            "config": {"workload": "bmSparse SpMV fp32, " + wl["name"], "rows": info["num_rows"], "nnz": info["nnz"],
