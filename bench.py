@@ -454,13 +454,23 @@ MAC_VARIANT = {0: "default kernel of the tc_version", 1: "block_mac_mfma32_kerne
 
 
 def stage_bytes(st, sort_bits):
-    """compulsory bytes of the symbolic stages for THIS pipeline's layout (8-byte packed C key + 8-byte task per surviving pair; DESIGN.md
-    section 4 states them next to SURVEY 8(d)'s figures for the reference's 16-byte tasks): per candidate pair / surviving task / C block."""
+    """compulsory bytes of the symbolic stages for THIS library's layouts (DESIGN.md section 4 states them next to SURVEY 8(d)'s figures
+    for the reference's 16-byte tasks): per candidate pair / surviving task / C block.  Keyed by the stage the time is charged to."""
     cand, surv, cb = st["task_list_size"], st["surviving_tasks"], st["c_blocks"]
+    if st["sort_path"] == 2 and st.get("mac_variant") == 3:
+        # row-merge, strip mode (rowmerge_symbolic_kernel + emit): key + bitmap of B's tile per candidate pair; C's column + bitmap to scratch
+        # (12 B), read back by the emit pass, C's key + bitmap + offset written (24 B).  T_3 holds all of it (T_9 is an allocation)
+        return {"T_3": 16 * cand + 48 * cb}
     if st["sort_path"] == 2:
-        # row-merge path (rowmerge.hip): ONE pass reads key + bitmap of B's tile for every candidate pair and writes C's key + bitmap once
-        # (scratch, then its final place); T_3 holds the whole pass, T_9 the popcount scan
-        return {"T_3": 16 * cand + 2 * 16 * cb + 12 * cb, "T_9": 16 * cb}
+        # row-merge, task-list mode (build + copy): 16 B per candidate pair; per surviving pair the parked {pair, product, order} written and
+        # read back (2 x 18 B), its task placed (8 B), its product ORed (8 B), the task copied to the list (8 + 8 B); per C tile column +
+        # first task + bitmap to scratch (16 B), read by the copy pass (16 B), key + bitmap + offset + first task written (28 B)
+        return {"T_3": 16 * cand + 68 * surv + 60 * cb}
+    if st["sort_path"] == 3:
+        # column windows (rowwindow.hip): one 16-byte record of B's tile per candidate pair in the count pass, its 8-byte half in each half
+        # of a round of the fill pass (the first steps of a wave stay in registers: counted once), the task written (8 B); per C tile
+        # column + count + bitmap to scratch (16 B), read back (16 B), key + bitmap + offset + first task written (28 B)
+        return {"T_3": 24 * cand + 8 * surv + 60 * cb}
     passes = -(-sort_bits // 9)
     return {
         "T_3": 16 * cand,                              # count pass: the two bitmaps of every candidate pair
@@ -470,6 +480,18 @@ def stage_bytes(st, sort_bits):
         "T_9": 32 * surv + 32 * cb,                    # key + task + two bitmap gathers per task; C bitmap written, read by the popcount scan, offset written
     }
 
+
+def stage_fracs(sb, t_us, stage_idx):
+    """(GB/s, fraction of the HBM peak) per stage with a byte formula.  A fraction above 1 means the formula charges bytes the stage does
+    not move any more (T_9 = 2.54) -- refused here instead of being printed."""
+    gbs, frac = {}, {}
+    for k, i in stage_idx:
+        if k not in sb or t_us[i] < 1.0:
+            continue
+        gbs[k] = round(sb[k] / t_us[i] / 1e3, 1)
+        frac[k] = round(sb[k] / t_us[i] / 1e3 / HBM_PEAK_GBS, 4)
+        assert frac[k] <= 1.0, "stage %s: %d bytes in %.1f us is above the HBM peak -- the byte formula is wrong" % (k, sb[k], t_us[i])
+    return gbs, frac
 
 
 def bench_spgemm(B, gen, np, args):
@@ -554,6 +576,7 @@ def bench_spgemm(B, gen, np, args):
         sort_bits = max(1, int(np.ceil(np.log2(max(2, (info["num_rows"] + 7) // 8))))) + max(1, int(np.ceil(np.log2(max(2, (info["num_cols"] + 7) // 8)))))
         sb = stage_bytes(best, sort_bits)
         stage_idx = (("T_1", 1), ("T_2", 2), ("T_3", 3), ("T_4", 4), ("T_5", 5), ("T_6", 6), ("T_9", 9), ("T_7", 7))
+        stage_gbs, stage_frac = stage_fracs(sb, best["t_us"], stage_idx)
         res.append({"workload": "bmSparse SpGEMM A*A %s, %s" % ("fp16 MFMA block-MAC" if dtype == B.F16 else "fp32", name),
                     "rows": info["num_rows"], "nnz": info["nnz"], "blocks": info["block_num"],
                     "values_per_tile": round(info["nnz"] / max(1, info["block_num"]), 2),
@@ -566,9 +589,9 @@ def bench_spgemm(B, gen, np, args):
                     "gflops": round(2.0 * P / t_total / 1e9, 2),
                     "gflops_with_prepare": round(2.0 * P / (t_total + prepare_ms * 1e-3) / 1e9, 2),
                     "stage_us": {k: round(best["t_us"][i], 1) for k, i in stage_idx},
-                    "stage_GBs": {k: round(sb[k] / max(best["t_us"][i], 1e-3) / 1e3, 1) for k, i in stage_idx if k in sb},
-                    "stage_frac_of_hbm_peak": {k: round(sb[k] / max(best["t_us"][i], 1e-3) / 1e3 / HBM_PEAK_GBS, 4) for k, i in stage_idx if k in sb},
-                    "sort_path": {0: "global radix", 1: "segmented", 2: "none (row-merge: C's structure formed per block-row in LDS)"}[best["sort_path"]],
+                    "stage_GBs": stage_gbs, "stage_frac_of_hbm_peak": stage_frac,
+                    "sort_path": {0: "global radix", 1: "segmented", 2: "none (row-merge: C's structure formed per block-row in LDS)",
+                                  3: "none (column windows: C's structure formed per block-row and window of block columns in dense LDS tables)"}[best["sort_path"]],
                     "roofline": roof})
         del A, At
         B.check(B.lib().bmsp_trim_pool())

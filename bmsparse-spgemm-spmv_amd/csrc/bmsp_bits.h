@@ -72,6 +72,43 @@ BMSP_HD uint64_t tile_product_bmp(uint64_t a, uint64_t bt)
     return res;
 }
 
+// 8x8 bit-matrix transpose of a tile bitmap (byte r of the word, top byte first, = row r; bit 7-c of the byte = column c): the row-major
+// form of a tile stored column-major (a `transposed` build, src/bmSpMatrix.cu:85-98) and vice versa.
+BMSP_HD uint64_t tile_transpose(uint64_t x)
+{
+    uint64_t t;
+    t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x ^= t ^ (t << 7);
+    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x ^= t ^ (t << 14);
+    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x ^= t ^ (t << 28);
+    return x;
+}
+
+// bmp_calculator (src/bmSparse_SPGEMM.cu:787-810) from A's bitmap (row-major) and B's ROW-major bitmap br = tile_transpose(bt):
+// C = OR_k (rows i with A(i,k)) x (row k of B); equals tile_product_bmp(a, bt).  On the device: per k, bit (7-k) of every byte of A is
+// moved to the byte's sign bit and the sign bits are spread over their bytes by v_perm_b32 (selectors 8..11 = sign of bytes 1 / 3 of S1,
+// 1 / 3 of S0), row k of B is replicated by another v_perm_b32: 11 full-rate instructions per k against ~25 (two 64-bit multiplies) for
+// tile_product_bmp -- the row-merge passes evaluate it for every surviving pair (bmsp_selftest_tile_product checks it on the hardware).
+BMSP_HD uint64_t tile_product_rm(uint64_t a, uint64_t br)
+{
+    const uint32_t ah = (uint32_t)(a >> 32), al = (uint32_t)a, bh = (uint32_t)(br >> 32), bl = (uint32_t)br;
+    uint32_t ch = 0, cl = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t sh = ah << k, sl = al << k;
+        const uint32_t mh = __builtin_amdgcn_perm(sh, sh << 8, 0x0B090A08u);
+        const uint32_t ml = __builtin_amdgcn_perm(sl, sl << 8, 0x0B090A08u);
+        const uint32_t rk = __builtin_amdgcn_perm(0u, k < 4 ? bh : bl, 0x01010101u * (uint32_t)(3 - (k & 3)));
+#else
+        const uint32_t mh = ((ah >> (7 - k)) & 0x01010101u) * 0xffu, ml = ((al >> (7 - k)) & 0x01010101u) * 0xffu;
+        const uint32_t rk = (((k < 4 ? bh : bl) >> (8 * (3 - (k & 3)))) & 0xffu) * 0x01010101u;
+#endif
+        ch |= mh & rk;
+        cl |= ml & rk;
+    }
+    return ((uint64_t)ch << 32) | (uint64_t)cl;
+}
+
 // double -> IEEE binary16 bits, round to nearest even in one step (what `(half)double` does in the
 // reference, src/bmSpMatrix.cu:141; include/half.hpp:373-374).
 BMSP_HD uint16_t f64_to_f16_bits(double x)

@@ -376,6 +376,8 @@ void free_matrix(bmsp_matrix_s *m)
     pool_free(m->spmv_chunks);
     pool_free(m->spmv_pos);
     pool_free(m->block_meta);
+    pool_free(m->sym_recs);
+    pool_free(m->col_index); pool_free(m->col_index_row);
     pool_free(m->dense_tiles);
     pool_free(m->lane_tiles);
     pool_free(m->sp_tasks); pool_free(m->sp_task_begin); pool_free(m->sp_c_of_wave);
@@ -401,6 +403,8 @@ void invalidate_matrix(bmsp_matrix_s *m, int structure_changed)
     pool_free(m->spmv_chunks); m->spmv_chunks = nullptr; m->spmv_num_chunks = 0; m->spmv_plan_long = 0; m->spmv_full_tiles = 0;
     pool_free(m->spmv_pos); m->spmv_pos = nullptr; m->spmv_tinfo = nullptr; m->spmv_eoff = nullptr; m->spmv_pos_base = 0; m->spmv_pos_count = 0; m->spmv_pos_tried = 0;
     pool_free(m->block_meta); m->block_meta = nullptr;
+    pool_free(m->sym_recs); m->sym_recs = nullptr;
+    pool_free(m->col_index); pool_free(m->col_index_row); m->col_index = nullptr; m->col_index_row = nullptr; m->col_index_tried = 0;
     free_matrix(m->shard_view); m->shard_view = nullptr; m->shard_world = 0; m->shard_rank = 0; m->shard_bounds.clear();
 }
 
@@ -453,6 +457,120 @@ void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st)
     if ((uint64_t)m->values_extent() >= (1ull << 32)) fail(BMSP_ERR_LIMIT, "packed block records hold 32-bit value offsets");
     m->block_meta = (uint32_t *)pool_alloc(16 * (size_t)(m->block_num ? m->block_num : 1));
     if (m->block_num) device_for_each(PackBlockMeta{m->bmps, m->offsets, m->block_meta}, (uint64_t)m->block_num, st);
+}
+
+namespace {
+struct PackSymRecs {
+    const uint64_t *keys, *bmps;
+    uint32_t *out;
+    __device__ void operator()(uint64_t b) const
+    {
+        const uint64_t bm = bmps[b], rm = tile_transpose(bm);
+        uint32_t *r = out + 4 * b;
+        r[0] = (uint32_t)rm; r[1] = (uint32_t)(rm >> 32); r[2] = key_col(keys[b]); r[3] = tile_or_bytes(bm);
+    }
+};
+// tile_product_rm(a, transpose(bt)) against tile_product_bmp(a, bt) on bitmaps of every density
+__global__ __launch_bounds__(kThreads) void tile_product_selftest_kernel(uint32_t n, uint32_t *bad)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    auto mix = [](uint64_t z) {
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    uint64_t a = mix(2ull * i), b = mix(2ull * i + 1);
+    for (uint32_t k = 0; k < i % 5; k++) a &= mix(a + k);
+    for (uint32_t k = 0; k < (i / 5) % 5; k++) b &= mix(b + k);
+    if (i % 97 == 0) a = ~0ull;
+    if (i % 89 == 0) b = ~0ull;
+    if (tile_product_rm(a, tile_transpose(b)) != tile_product_bmp(a, b)) atomicAdd(bad, 1u);
+}
+}  // namespace
+
+// {row-major bitmap, block column, rows in use} of every tile of a right operand (stored column-major): built once per matrix, like the
+// block records
+void ensure_sym_recs(bmsp_matrix_s *m, hipStream_t st)
+{
+    if (m->sym_recs) return;
+    m->sym_recs = (uint32_t *)pool_alloc(16 * (size_t)(m->block_num ? m->block_num : 1));
+    if (m->block_num) device_for_each(PackSymRecs{m->keys, m->bmps, m->sym_recs}, (uint64_t)m->block_num, st);
+}
+
+namespace {
+struct IdxEntriesIn {
+    const uint32_t *rowptr;
+    uint64_t rows;
+    uint32_t per_row;
+    __device__ uint64_t operator()(uint64_t k) const { return k < rows && rowptr[k + 1] - rowptr[k] > kIdxMinLen ? (uint64_t)per_row : 0ull; }
+};
+struct IdxRowOut {
+    const uint32_t *rowptr;
+    uint32_t *idx_row;
+    uint64_t rows;
+    uint64_t *total;
+    __device__ void operator()(uint64_t k, uint64_t ex) const
+    {
+        if (k == rows) { *total = ex; return; }
+        idx_row[k] = rowptr[k + 1] - rowptr[k] > kIdxMinLen ? (uint32_t)ex : ~0u;
+    }
+};
+// one thread per (block-row, grid column): first tile of the block-row at or beyond the column
+struct FillColIndex {
+    const uint64_t *keys;
+    const uint32_t *rowptr, *idx_row;
+    uint32_t *idx;
+    uint32_t per_row, gran;
+    __device__ void operator()(uint64_t i) const
+    {
+        const uint32_t k = (uint32_t)(i / per_row), q = (uint32_t)(i % per_row);
+        const uint32_t off = idx_row[k];
+        if (off == ~0u) return;
+        uint32_t lo = rowptr[k], hi = rowptr[k + 1];
+        const uint64_t col = (uint64_t)q * gran;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if ((uint64_t)key_col(keys[mid]) < col) lo = mid + 1;
+            else hi = mid;
+        }
+        idx[off + q] = lo;
+    }
+};
+}  // namespace
+
+// Column index of the block-rows longer than kIdxMinLen tiles, on a grid of `gran` block columns: built once per matrix (right operands of
+// the column-window passes: every window of every block-row of A that meets a long block-row of B cuts it at two grid columns).  Left
+// unbuilt (col_index_row stays null, the passes search) when it would exceed 256 MB.
+void ensure_col_index(bmsp_matrix_s *m, uint32_t gran, hipStream_t st)
+{
+    if (m->col_index_tried && m->col_index_gran == gran) return;
+    pool_free(m->col_index); pool_free(m->col_index_row);
+    m->col_index = nullptr; m->col_index_row = nullptr;
+    m->col_index_tried = 1; m->col_index_gran = gran;
+    ensure_rowptr(m, st);
+    const uint64_t rows = (uint64_t)m->num_block_rows();
+    const uint64_t per_row = ((uint64_t)m->num_block_cols() + gran - 1) / gran + 1;
+    if (rows == 0 || per_row >= (1ull << 20) || rows * per_row >= (1ull << 40)) return;
+    DevBuf<uint32_t> idx_row(rows + 1);
+    HostScalar<uint64_t> total_h;
+    device_exclusive_scan<uint64_t>(IdxEntriesIn{m->rowptr, rows, (uint32_t)per_row}, IdxRowOut{m->rowptr, idx_row.p, rows, total_h.dev()}, rows + 1, st);
+    const uint64_t total = total_h.wait(st);
+    if (total * 4 > (256ull << 20)) return;
+    m->col_index = (uint32_t *)pool_alloc(4 * (size_t)(total ? total : 1));
+    m->col_index_row = idx_row.take();
+    if (total) device_for_each(FillColIndex{m->keys, m->rowptr, m->col_index_row, m->col_index, (uint32_t)per_row, gran}, rows * per_row, st);
+}
+
+int tile_product_selftest(hipStream_t st)
+{
+    DevBuf<uint32_t> bad(1);
+    BMSP_HIP(hipMemsetAsync(bad.p, 0, 4, st));
+    const uint32_t n = 1u << 20;
+    hipLaunchKernelGGL(tile_product_selftest_kernel, dim3(n / kThreads), dim3(kThreads), 0, st, n, bad.p);
+    BMSP_CHECK_LAUNCH();
+    return (int)read_back(bad.p, st);
 }
 
 void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st)

@@ -567,6 +567,14 @@ int bmsp_selftest_mfma_layout(int *mismatches)
     BMSP_API_END
 }
 
+int bmsp_selftest_tile_product(int *mismatches)
+{
+    BMSP_API_BEGIN
+    need(mismatches, "mismatches");
+    *mismatches = tile_product_selftest(nullptr);
+    BMSP_API_END
+}
+
 int bmsp_selftest_mfma_f32_chain(int *mismatches)
 {
     BMSP_API_BEGIN

@@ -35,11 +35,17 @@ struct bmsp_matrix_s {
     int spmv_pos_tried = 0;
     // (bitmap, value offset) of every block as one 16-byte record, for kernels that gather both (block-MAC): built lazily
     uint32_t *block_meta = nullptr;  // block_num x {bmp lo, bmp hi, offset in elements, 0}
+    uint32_t *sym_recs = nullptr;    // right operands: block_num x {bitmap ROW-major (lo, hi), block column, rows the tile uses}: all the column-window passes (rowwindow.hip) read per candidate pair
+    // column index of the long block-rows (right operands of the column-window passes): col_index[col_index_row[k] + c / col_index_gran] = first
+    // tile of block-row k whose block column is >= c; col_index_row[k] = ~0 for block-rows of at most kIdxMinLen tiles
+    uint32_t *col_index = nullptr, *col_index_row = nullptr;
+    uint32_t col_index_gran = 0;
+    int col_index_tried = 0;
     // fp16 matrices: every tile expanded to 64 halves in position order (128 B per block), for the K = 32 MFMA block-MAC: built lazily
     void *dense_tiles = nullptr;
     void *lane_tiles = nullptr;   // fp32 matrices: tiles in the lane order of the fp32 MFMA block-MAC (256 B per block): built lazily
     // SpGEMM row-merge paths: the right operand (keys pointer, block count) this matrix was last multiplied with and what that product
-    // turned out to need (1 strip mode, 2 task-list mode, 3 the pipeline) -- the next product of the pair goes there directly
+    // turned out to need (1 strip mode, 2 task-list mode, 3 the pipeline, 4 column windows) -- the next product of the pair goes there directly
     const void *rm_partner_keys = nullptr;
     int64_t rm_partner_blocks = 0;
     int rm_partner_mode = 0;
@@ -107,6 +113,10 @@ bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, co
 void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st);
 void ensure_row_stats(bmsp_matrix_s *m, hipStream_t st);
 void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st);
+void ensure_sym_recs(bmsp_matrix_s *m, hipStream_t st);
+void ensure_col_index(bmsp_matrix_s *m, uint32_t gran, hipStream_t st);
+constexpr uint32_t kIdxMinLen = 16;
+int tile_product_selftest(hipStream_t st);
 void ensure_dense_tiles(bmsp_matrix_s *m, hipStream_t st);
 void ensure_lane_tiles(bmsp_matrix_s *m, hipStream_t st);
 void ensure_finite_flag(bmsp_matrix_s *m, hipStream_t st);
@@ -127,6 +137,8 @@ void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipS
 bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, uint32_t row_cap,
                        uint64_t *surviving, uint64_t *candidates, hipStream_t st);
 bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, DevBuf<uint64_t> &tasks,
+                       DevBuf<uint32_t> &task_begin, DevBuf<uint32_t> &c_of_wave, uint64_t *n_tasks, hipStream_t st);
+bool rowmerge_windowed(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, DevBuf<uint64_t> &tasks,
                        DevBuf<uint32_t> &task_begin, DevBuf<uint32_t> &c_of_wave, uint64_t *n_tasks, hipStream_t st);
 void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hipStream_t st);
 void matrix_to_coo_device_split(bmsp_matrix_s *m, int *d_rows, int *d_cols, double *d_vals, hipStream_t st);

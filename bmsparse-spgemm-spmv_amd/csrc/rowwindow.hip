@@ -1,0 +1,595 @@
+// rowwindow.hip -- C's structure AND the sorted task list of A x B for operands with hub block-rows (power-law graphs: R-MAT), where a
+// block-row of C holds thousands of tiles: one WORKGROUP per (block-row of A, window of C's block columns), dense tables in LDS indexed by
+// the column inside the window.
+//
+// Reference: bmSparse_mult (src/bmSparse_SPGEMM.cu:849-1164) expands every candidate pair (:884-932), filters (:742-757, :944-948), sorts
+// the survivors by C key (:963-1024; bb_segsort's bin for segments > 2048, include/bb_segsort-master/bb_comput_l.h:1155-1284), reduces the
+// keys (:1040-1062) and ORs the tile products (:787-810, :1067-1107).  rowmerge.hip forms a block-row of C in a wave's hash table and
+// stops at ~900 tiles per block-row; on R-MAT 2^16 x 8 a block-row of C holds 1700 tiles on average (C is a fifth full at tile
+// granularity) and every product went to the expand - sort - compress pipeline (5 ms of candidate-sized passes).  Here the SORT is replaced
+// by addressing: inside a window of at most kWinSlots block columns a C tile's slot is (column - window start), so
+//   * count pass: every surviving pair bumps its column's task count and ORs its tile product into the column's bitmap (LDS atomics, any
+//     order); the non-empty columns, in slot order = C's key order, are the window's C tiles;
+//   * fill pass: the tasks of a C tile must appear in ascending A tile (V15's summation order, :269-273).  The A tiles of the block-row
+//     are taken 64 at a time; a surviving pair sets bit (A tile - first of the round) in its column's 64-bit hit mask; after a barrier
+//     its place inside the C tile is (tasks of earlier rounds) + popcount(hit mask below its bit) -- no order dependence between waves.
+// Long block-rows are cut into more windows than the tables need (<= kWinCand candidate pairs per window on a uniform split), so a hub
+// block-row is spread over many workgroups.  The result is the pipeline's, bit for bit: keys, bitmaps, offsets, task order.
+#include "matrix.h"
+#include "prims.hip.h"
+#include "bmsp_bits.h"
+
+namespace bmsp {
+namespace {
+
+constexpr int kWinSlots = 2048;           // block columns per window (dense table entries)
+constexpr uint32_t kWinCand = 16u << 10;  // candidate pairs per window a block-row is cut for (uniform split of its columns)
+constexpr uint32_t kWinGran = 64;         // window edges are multiples of it: B's column index (builder.hip: ensure_col_index) answers them with one load
+static_assert(kWinSlots % kWinGran == 0, "a full-width window ends on the grid");
+constexpr uint32_t kWinMaxPerRow = 16;    // widest operand taken: kWinMaxPerRow windows cover B's block columns
+
+struct WinUnit {
+    uint32_t row, lo, hi;  // block-row of A / C, block columns [lo, hi) of C
+    uint32_t scr;          // first scratch slot of the window's tile list (hi - lo slots)
+};
+
+// windows of a block-row with `cand` candidate pairs over `ncols` block columns
+__host__ __device__ __forceinline__ uint32_t win_width(uint64_t cand, uint32_t ncols, uint32_t cw)
+{
+    uint64_t n = (ncols + (uint32_t)kWinSlots - 1) / (uint32_t)kWinSlots;
+    const uint64_t by_work = (cand + cw - 1) / cw;
+    if (by_work > n) n = by_work;
+    uint32_t w = (uint32_t)((ncols + n - 1) / n);
+    w = (w + kWinGran - 1u) / kWinGran * kWinGran;  // window edges sit on the column index's grid (matrix.h: col_index)
+    if (w > (uint32_t)kWinSlots) w = (uint32_t)kWinSlots;
+    return w;
+}
+__host__ __device__ __forceinline__ uint32_t win_count(uint64_t cand, uint32_t ncols, uint32_t cw)
+{
+    if (cand == 0 || ncols == 0) return 0;
+    const uint32_t w = win_width(cand, ncols, cw);
+    return (ncols + w - 1) / w;
+}
+
+struct RowCand {
+    const uint64_t *first_pos;
+    const uint32_t *a_rowptr;
+    __device__ uint64_t operator()(uint64_t i) const { return first_pos[a_rowptr[i + 1]] - first_pos[a_rowptr[i]]; }
+};
+struct PlanUnitsIn {
+    RowCand rc;
+    uint64_t rows;
+    uint32_t ncols, cw;
+    __device__ uint32_t operator()(uint64_t i) const { return i < rows ? win_count(rc(i), ncols, cw) : 0u; }
+};
+struct PlanScratchIn {
+    RowCand rc;
+    uint64_t rows;
+    uint32_t ncols;
+    __device__ uint64_t operator()(uint64_t i) const { return i < rows && rc(i) ? (uint64_t)ncols : 0ull; }  // the windows of a block-row tile its columns
+};
+struct EmitUnits {
+    RowCand rc;
+    uint32_t ncols, cw;
+    const uint32_t *unit_first;
+    const uint64_t *scr_first;
+    WinUnit *units;
+    __device__ void operator()(uint64_t i) const
+    {
+        const uint64_t cand = rc(i);
+        const uint32_t n = win_count(cand, ncols, cw);
+        if (!n) return;
+        const uint32_t w = win_width(cand, ncols, cw), u0 = unit_first[i];
+        for (uint32_t q = 0; q < n; q++) {
+            const uint32_t lo = q * w, hi = lo + w < ncols ? lo + w : ncols;
+            units[u0 + q] = WinUnit{(uint32_t)i, lo, hi, (uint32_t)(scr_first[i] + lo)};
+        }
+    }
+};
+
+struct WinArgs {
+    const uint64_t *a_keys, *a_bmps;
+    const uint32_t *a_join;   // per A tile {B's block-row of its column: first tile, one past the last, place of that block-row's column index (~0: none), 0}
+    const uint32_t *a_rowptr;
+    const uint64_t *b_keys, *b_bmps;
+    const uint32_t *b_recs;   // per B tile {bitmap row-major (lo, hi), block column, rows the tile uses}: all a pass needs, one 16-byte load
+    const uint32_t *b_rowptr;
+    const uint32_t *b_idx_row, *b_idx;  // column index of B's long block-rows (null: binary search): b_idx[b_idx_row[k] + c / kWinGran] = first tile of block-row k with column >= c
+    uint32_t b_block_rows;
+    const WinUnit *units;
+    uint32_t n_units;
+    // tile lists of the windows (count pass -> fill pass), at WinUnit::scr: column, tasks, bitmap of every C tile in column order
+    uint32_t *t_col, *t_cnt;
+    uint64_t *t_bmp;
+    uint32_t *u_tiles, *u_surv, *u_nnz;  // per window: C tiles, surviving pairs, values
+    // fill pass
+    const uint32_t *tile_base, *task_base;  // per window: first C tile, first task
+    const uint64_t *val_base;               //             first value
+    uint64_t *c_keys, *c_bmps, *c_offs;
+    uint32_t *task_begin;
+    uint64_t *tasks;
+};
+
+constexpr int kWinWaves = 8;                    // waves per workgroup
+constexpr int kWinThreads = 64 * kWinWaves;
+constexpr int kWinTiles = 64 / kWinWaves;       // A tiles of a round (64) a wave looks up; their lanes (64 / kWinTiles each) work together
+constexpr int kWinLanes = 64 / kWinTiles;
+constexpr int kWinBatch = 4;                    // steps whose records a wave requests together, fill pass (8-byte half records)
+constexpr int kWinBatchCount = 4;               // ... count pass (16-byte records)
+
+// A ROUND = 64 consecutive A tiles of the block-row.  Their stretches of B's block-rows inside the window are cut into STEPS of 64 tiles;
+// the round's steps are dealt to the workgroup's waves in turn (step i to wave i mod 8), so that one hub block-row of B among the 64
+// does not leave seven waves waiting at the round's barrier, and a wave requests the records of several steps -- of whatever A tiles --
+// together (the passes are bound by memory round trips: ~1.5 us each under load, measured).
+struct alignas(16) RoundTable {
+    uint32_t seg[64];   // first tile of B's block-row k inside the window
+    uint32_t len[64];   // tiles of it inside the window = candidate pairs of the A tile
+    uint64_t abm[64];
+};
+
+// first tile in [lo, hi) whose block column is >= col; the kWinLanes lanes of a group (same lo, hi, col; sub = lane inside the group,
+// shift = first lane of the group) probe kWinLanes interior points per round trip (operands whose column index was not built)
+__device__ __forceinline__ uint32_t lower_bound_col_group(const uint64_t *keys, uint32_t lo, uint32_t hi, uint32_t col, uint32_t sub, uint32_t shift)
+{
+    while (__any(lo < hi)) {
+        const uint32_t n = hi > lo ? hi - lo : 0u;
+        bool less = false;
+        if (n) less = key_col(keys[lo + (n * (sub + 1u)) / (uint32_t)(kWinLanes + 1)]) < col;
+        const uint32_t c = (uint32_t)__popcll((__ballot(less) >> shift) & ((1ull << kWinLanes) - 1ull));  // probes below col: the lower ones (keys ascend)
+        if (n) {
+            const uint32_t nlo = c ? lo + (n * c) / (uint32_t)(kWinLanes + 1) + 1u : lo;
+            const uint32_t nhi = c < (uint32_t)kWinLanes ? lo + (n * (c + 1u)) / (uint32_t)(kWinLanes + 1) : hi;
+            lo = nlo; hi = nhi;
+        }
+    }
+    return lo;
+}
+
+typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
+
+// wave w's share of the round's look-ups: A tiles r0 + 8 w ... + 7 (those below a1): B's block-row cut to the window.  One load of the A
+// tile's join record {B's block-row: first tile, one past the last, place of its column index}, then: long block-rows answer from the
+// column index (two loads), short ones (<= kIdxMinLen tiles = two per lane of the group) are looked at whole.
+__device__ __forceinline__ void round_prologue(const WinArgs &g, const WinUnit &u, uint32_t ncols_all, RoundTable &R, uint32_t r0, uint32_t a1, int w, int lane)
+{
+    const uint32_t tile = (uint32_t)lane / (uint32_t)kWinLanes, sub = (uint32_t)lane % (uint32_t)kWinLanes, shift = tile * (uint32_t)kWinLanes;
+    const uint32_t v = (uint32_t)(kWinTiles * w) + tile, a = r0 + v;
+    uint32_t bb = 0, be = 0, off = ~0u;
+    uint64_t abm = 0;
+    if (a < a1) {
+        const u32x4w j = ((const u32x4w *)g.a_join)[a];
+        abm = g.a_bmps[a];
+        bb = j[0]; be = j[1]; off = j[2];
+    }
+    uint32_t s0, s1;
+    if (g.b_idx) {  // (kernel-uniform)
+        const bool cut_lo = u.lo != 0u, cut_hi = u.hi < ncols_all;
+        s0 = bb; s1 = be;
+        if (off != ~0u) {
+            if (cut_lo) s0 = g.b_idx[off + u.lo / kWinGran];
+            if (cut_hi) s1 = g.b_idx[off + u.hi / kWinGran];
+        }
+        // short block-rows: every lane of the group looks at two tiles; tiles below an edge = where the edge cuts
+        const bool small = off == ~0u && be > bb;
+        uint32_t c0 = ~0u, c1 = ~0u;
+        if (small && bb + sub < be) c0 = key_col(g.b_keys[bb + sub]);
+        if (small && bb + (uint32_t)kWinLanes + sub < be) c1 = key_col(g.b_keys[bb + (uint32_t)kWinLanes + sub]);
+        const uint64_t gm = (1ull << kWinLanes) - 1ull;
+        const uint32_t below_lo = (uint32_t)__popcll((__ballot(c0 < u.lo) >> shift) & gm) + (uint32_t)__popcll((__ballot(c1 < u.lo) >> shift) & gm);
+        const uint32_t below_hi = (uint32_t)__popcll((__ballot(c0 < u.hi) >> shift) & gm) + (uint32_t)__popcll((__ballot(c1 < u.hi) >> shift) & gm);
+        if (small) { s0 = bb + below_lo; s1 = bb + below_hi; }
+    } else {
+        s0 = u.lo ? lower_bound_col_group(g.b_keys, bb, be, u.lo, sub, shift) : bb;
+        s1 = u.hi < ncols_all ? lower_bound_col_group(g.b_keys, s0, be, u.hi, sub, shift) : be;
+    }
+    if (sub == 0) { R.seg[v] = s0; R.len[v] = s1 - s0; R.abm[v] = abm; }
+}
+
+// what a wave keeps of the round after the barrier: lane v holds A tile v of the round; P = steps of the round in front of the tile
+struct RoundRegs {
+    uint32_t seg, len, alo, ahi, P;
+    uint32_t S;  // steps of the round (uniform)
+};
+__device__ __forceinline__ RoundRegs round_regs(const RoundTable &R, int lane)
+{
+    RoundRegs q;
+    q.seg = R.seg[lane]; q.len = R.len[lane];
+    const uint64_t a = R.abm[lane];
+    q.alo = (uint32_t)a; q.ahi = (uint32_t)(a >> 32);
+    const uint32_t steps = (q.len + 63u) >> 6;
+    const uint32_t inc = wave_inclusive_sum(steps);
+    q.P = inc - steps;
+    q.S = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    return q;
+}
+
+// One A tile per step, 64 tiles of B's block-row: everything that depends on the A tile alone -- its bitmap, the columns it uses, the
+// byte masks of bmp_calculator -- is wave-uniform (scalar registers, scalar ALU), and a lane is left with one record load, the filter
+// (one AND) and its table update.  (A first form laid the stretches of 8 or 16 A tiles end to end, 64 pairs per step whatever the
+// tile: every lane then ran the whole 8x8 boolean product -- 130 vector instructions per step, 411 M per product on R-MAT 2^16.)
+struct StepScalars {
+    uint32_t v, s0, len, x0, ah, al, cols;  // A tile of the round, its stretch, first pair of the step, its bitmap, its columns in use
+    bool ok;
+};
+__device__ __forceinline__ StepScalars step_scalars(const RoundRegs &q, uint32_t i)
+{
+    StepScalars t{};
+    t.ok = i < q.S;
+    if (t.ok) {
+        // last A tile whose first step is <= i (tiles without a step share their start with the next tile: the last of a run owns it)
+        t.v = (uint32_t)__popcll(__ballot(q.P <= i)) - 1u;
+        t.s0 = (uint32_t)__builtin_amdgcn_readlane((int)q.seg, (int)t.v);
+        t.len = (uint32_t)__builtin_amdgcn_readlane((int)q.len, (int)t.v);
+        t.x0 = (i - (uint32_t)__builtin_amdgcn_readlane((int)q.P, (int)t.v)) << 6;
+        t.ah = (uint32_t)__builtin_amdgcn_readlane((int)q.ahi, (int)t.v);
+        t.al = (uint32_t)__builtin_amdgcn_readlane((int)q.alo, (int)t.v);
+        t.cols = tile_or_bytes(((uint64_t)t.ah << 32) | (uint64_t)t.al);  // bit 7-k: column k of the A tile holds a value
+    }
+    return t;
+}
+
+// bmp_calculator (:787-810) for one lane's B tile (row-major bitmap br) against the wave's A tile: C = OR_k (rows i with A(i,k)) x (row k
+// of B), over the columns k the A tile uses; the A side is scalar
+__device__ __forceinline__ uint64_t tile_product_scalar_a(const StepScalars &t, uint32_t bh, uint32_t bl)
+{
+    uint32_t ch = 0, cl = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if ((t.cols >> (7 - k)) & 1u) {  // (wave-uniform)
+            const uint32_t mh = ((t.ah >> (7 - k)) & 0x01010101u) * 0xffu, ml = ((t.al >> (7 - k)) & 0x01010101u) * 0xffu;
+            const uint32_t rk = __builtin_amdgcn_perm(0u, k < 4 ? bh : bl, 0x01010101u * (uint32_t)(3 - (k & 3)));
+            ch |= mh & rk;
+            cl |= ml & rk;
+        }
+    }
+    return ((uint64_t)ch << 32) | (uint64_t)cl;
+}
+
+// exclusive scan of one value per thread across the kWinThreads-thread workgroup (lds: kWinWaves words; two barriers inside)
+__device__ __forceinline__ uint32_t win_block_exclusive_sum(uint32_t v, uint32_t *lds, uint32_t &total)
+{
+    const uint32_t inc = wave_inclusive_sum(v);
+    if (lane_id() == kWave - 1) lds[wave_id()] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWinWaves; w++) {
+        const uint32_t s = lds[w];
+        if (w < wave_id()) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+// ---- count pass: C tiles of the window (columns, task counts, bitmaps) -------------------------------------------------------------------
+// Windows are taken in launch order: consecutive workgroups go to different XCDs, so the hub block-rows of a power-law operand (its first
+// block-rows: R-MAT's first eighth of the rows carries half of the candidate pairs) are spread over all eight.  (An XCD-contiguous
+// assignment, as the row-merge passes use for banded operands, gave one XCD half of the work: 2.9 + 3.9 ms instead of 1.9 + 2.6 ms.)
+template <int T>
+__global__ __launch_bounds__(kWinThreads) void rowwin_count_kernel(WinArgs g, uint32_t ncols_all)
+{
+    __shared__ uint32_t cnt[T];
+    __shared__ uint64_t bmp[T];
+    __shared__ RoundTable rt[2];
+    __shared__ uint32_t red[kWinWaves], red2[2 * kWinWaves];
+    constexpr int PT = T / kWinThreads;
+    const uint32_t unit = blockIdx.x;
+    const WinUnit u = g.units[unit];
+    const int w = wave_id(), lane = lane_id();
+    for (int s = threadIdx.x; s < T; s += kWinThreads) { cnt[s] = 0u; bmp[s] = 0ull; }
+    const uint32_t a0 = g.a_rowptr[u.row], a1 = g.a_rowptr[u.row + 1];
+    const u32x4w *recs = (const u32x4w *)g.b_recs;
+    for (uint32_t r0 = a0, par = 0; r0 < a1; r0 += 64u, par ^= 1u) {
+        round_prologue(g, u, ncols_all, rt[par], r0, a1, w, lane);
+        __syncthreads();  // (also orders the table's zeroing before the first update; the other round table is free again: every wave has its copy)
+        const RoundRegs q = round_regs(rt[par], lane);
+        for (uint32_t i0 = (uint32_t)w; i0 < q.S; i0 += (uint32_t)(kWinWaves * kWinBatchCount)) {
+            StepScalars t[kWinBatchCount];
+            u32x4w r[kWinBatchCount];
+#pragma unroll
+            for (int b = 0; b < kWinBatchCount; b++) {
+                t[b] = step_scalars(q, i0 + (uint32_t)(kWinWaves * b));
+                r[b] = u32x4w{0u, 0u, 0u, 0u};
+                if (t[b].ok && t[b].x0 + (uint32_t)lane < t[b].len) r[b] = recs[t[b].s0 + t[b].x0 + (uint32_t)lane];
+            }
+#pragma unroll
+            for (int b = 0; b < kWinBatchCount; b++) {
+                // multiplication_checker (:742-757): a column of the A tile meets a row of the B tile (no record beyond the stretch: rows in use = 0)
+                if (t[b].ok && (t[b].cols & r[b][3])) {
+                    const uint32_t slot = r[b][2] - u.lo;
+                    atomicAdd(&cnt[slot], 1u);
+                    atomicOr((unsigned long long *)&bmp[slot], (unsigned long long)tile_product_scalar_a(t[b], r[b][1], r[b][0]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // the non-empty columns in slot order: thread t owns slots [PT t, PT t + PT)
+    uint32_t mine = 0, sv = 0, nz = 0;
+#pragma unroll
+    for (int i = 0; i < PT; i++) {
+        const uint32_t c = cnt[threadIdx.x * PT + i];
+        mine += c ? 1u : 0u;
+        sv += c;
+        nz += (uint32_t)__popcll(bmp[threadIdx.x * PT + i]);
+    }
+    uint32_t tiles;
+    uint32_t pos = u.scr + win_block_exclusive_sum(mine, red, tiles);
+#pragma unroll
+    for (int i = 0; i < PT; i++) {
+        const uint32_t s = threadIdx.x * PT + i, c = cnt[s];
+        if (c) {
+            g.t_col[pos] = u.lo + s;
+            g.t_cnt[pos] = c;
+            g.t_bmp[pos] = bmp[s];
+            pos++;
+        }
+    }
+    sv = wave_sum(sv); nz = wave_sum(nz);
+    if (lane == 0) { red2[w] = sv; red2[kWinWaves + w] = nz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s1 = 0, s2 = 0;
+        for (int b = 0; b < kWinWaves; b++) { s1 += red2[b]; s2 += red2[kWinWaves + b]; }
+        g.u_tiles[unit] = tiles;
+        g.u_surv[unit] = s1;
+        g.u_nnz[unit] = s2;
+    }
+}
+
+// ---- fill pass: C's arrays for the window's tiles, and its tasks in (column, A tile) order ------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g, uint32_t ncols_all)
+{
+    __shared__ uint32_t begin[T];    // first free task slot of the column's C tile, relative to the window's first task
+    __shared__ uint64_t hit2[2][T];  // A tiles of the round (bit = A tile - the round's first) that meet the column; rounds alternate between the two
+    __shared__ RoundTable rt[2];
+    __shared__ uint32_t red[kWinWaves];
+    constexpr int PT = T / kWinThreads;
+    const uint32_t unit = blockIdx.x;
+    const uint32_t n = g.u_tiles[unit];
+    if (n == 0) return;
+    const WinUnit u = g.units[unit];
+    const int w = wave_id(), lane = lane_id();
+    const uint32_t tb = g.tile_base[unit], kb = g.task_base[unit];
+    const uint64_t vb = g.val_base[unit];
+    for (int s = threadIdx.x; s < T; s += kWinThreads) { hit2[0][s] = 0ull; hit2[1][s] = 0ull; }
+    // the window's tile list -> C's arrays; thread t owns tiles [PT t, PT t + PT)
+    {
+        uint32_t col[PT], c[PT];
+        uint64_t bm[PT];
+        uint32_t sc = 0, sn = 0;
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            const uint32_t r = threadIdx.x * PT + i;
+            col[i] = 0; c[i] = 0; bm[i] = 0;
+            if (r < n) { col[i] = g.t_col[u.scr + r]; c[i] = g.t_cnt[u.scr + r]; bm[i] = g.t_bmp[u.scr + r]; }
+            sc += c[i];
+            sn += (uint32_t)__popcll(bm[i]);
+        }
+        uint32_t tot;
+        uint32_t ec = win_block_exclusive_sum(sc, red, tot);
+        uint32_t en = win_block_exclusive_sum(sn, red, tot);
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            const uint32_t r = threadIdx.x * PT + i;
+            if (r < n) {
+                g.c_keys[tb + r] = key_make(u.row, col[i]);
+                g.c_bmps[tb + r] = bm[i];
+                g.c_offs[tb + r] = vb + (uint64_t)en;   // T_9's popcount scan (:1113-1130)
+                g.task_begin[tb + r] = kb + ec;          // T_6's task ranges (:1040-1062)
+                begin[col[i] - u.lo] = ec;
+            }
+            ec += c[i];
+            en += (uint32_t)__popcll(bm[i]);
+        }
+    }
+    const uint32_t a0 = g.a_rowptr[u.row], a1 = g.a_rowptr[u.row + 1];
+    const u32x2w *recs = (const u32x2w *)g.b_recs;  // {block column, rows the tile uses} = the upper half of a record
+    for (uint32_t r0 = a0, par = 0; r0 < a1; r0 += 64u, par ^= 1u) {
+        round_prologue(g, u, ncols_all, rt[par], r0, a1, w, lane);
+        __syncthreads();  // the round's look-ups are in; the previous round's second half is over (and C's arrays / `begin` are written)
+        const RoundRegs q = round_regs(rt[par], lane);
+        uint64_t *const hit = hit2[par];
+        // the previous round's marks become task slots taken, while this round's first records travel
+        StepScalars t0[kWinBatch];
+        u32x2w f[kWinBatch];
+#pragma unroll
+        for (int b = 0; b < kWinBatch; b++) {
+            t0[b] = step_scalars(q, (uint32_t)w + (uint32_t)(kWinWaves * b));
+            f[b] = u32x2w{0u, 0u};
+            if (t0[b].ok && t0[b].x0 + (uint32_t)lane < t0[b].len) f[b] = recs[2u * (t0[b].s0 + t0[b].x0 + (uint32_t)lane) + 1u];
+        }
+        if (r0 != a0) {
+            uint64_t *const prev = hit2[par ^ 1u];
+            for (int s = threadIdx.x; s < T; s += kWinThreads) {
+                const uint64_t h = prev[s];
+                if (h) { begin[s] += (uint32_t)__popcll(h); prev[s] = 0ull; }
+            }
+        }
+        // first half: the round's A tiles mark the columns they reach.  The wave's first kWinBatch steps stay in registers for the second half.
+#pragma unroll
+        for (int b = 0; b < kWinBatch; b++)
+            if (t0[b].ok && (t0[b].cols & f[b][1])) atomicOr((unsigned long long *)&hit[f[b][0] - u.lo], 1ull << t0[b].v);
+        for (uint32_t i0 = (uint32_t)w + (uint32_t)(kWinWaves * kWinBatch); i0 < q.S; i0 += (uint32_t)(kWinWaves * kWinBatch)) {
+            StepScalars t[kWinBatch];
+            u32x2w r[kWinBatch];
+#pragma unroll
+            for (int b = 0; b < kWinBatch; b++) {
+                t[b] = step_scalars(q, i0 + (uint32_t)(kWinWaves * b));
+                r[b] = u32x2w{0u, 0u};
+                if (t[b].ok && t[b].x0 + (uint32_t)lane < t[b].len) r[b] = recs[2u * (t[b].s0 + t[b].x0 + (uint32_t)lane) + 1u];
+            }
+#pragma unroll
+            for (int b = 0; b < kWinBatch; b++)
+                if (t[b].ok && (t[b].cols & r[b][1])) atomicOr((unsigned long long *)&hit[r[b][0] - u.lo], 1ull << t[b].v);
+        }
+        __syncthreads();
+        // second half: a pair's place inside its C tile = tasks of earlier rounds + marks of smaller A tiles of this round
+        auto place = [&](const StepScalars &t, const u32x2w &r) {
+            if (t.ok && (t.cols & r[1])) {
+                const uint32_t slot = r[0] - u.lo;
+                g.tasks[kb + begin[slot] + (uint32_t)__popcll(hit[slot] & ((1ull << t.v) - 1ull))] =
+                    ((uint64_t)(r0 + t.v) << 32) | (uint64_t)(t.s0 + t.x0 + (uint32_t)lane);
+            }
+        };
+#pragma unroll
+        for (int b = 0; b < kWinBatch; b++) place(step_scalars(q, (uint32_t)w + (uint32_t)(kWinWaves * b)), f[b]);
+        for (uint32_t i0 = (uint32_t)w + (uint32_t)(kWinWaves * kWinBatch); i0 < q.S; i0 += (uint32_t)(kWinWaves * kWinBatch)) {
+            StepScalars t[kWinBatch];
+            u32x2w r[kWinBatch];
+#pragma unroll
+            for (int b = 0; b < kWinBatch; b++) {
+                t[b] = step_scalars(q, i0 + (uint32_t)(kWinWaves * b));
+                r[b] = u32x2w{0u, 0u};
+                if (t[b].ok && t[b].x0 + (uint32_t)lane < t[b].len) r[b] = recs[2u * (t[b].s0 + t[b].x0 + (uint32_t)lane) + 1u];
+            }
+#pragma unroll
+            for (int b = 0; b < kWinBatch; b++) place(t[b], r[b]);
+        }
+    }
+}
+
+struct JoinA {
+    const uint64_t *a_keys;
+    const uint32_t *b_rowptr, *b_idx_row;
+    uint32_t b_block_rows;
+    uint32_t *out;
+    __device__ void operator()(uint64_t a) const
+    {
+        const uint32_t k = key_col(a_keys[a]);
+        uint32_t bb = 0, be = 0, off = ~0u;
+        if (k < b_block_rows) {
+            bb = b_rowptr[k]; be = b_rowptr[k + 1];
+            if (b_idx_row) off = b_idx_row[k];
+        }
+        uint32_t *r = out + 4 * a;
+        r[0] = bb; r[1] = be; r[2] = off; r[3] = 0u;
+    }
+};
+struct CntU32In {
+    const uint32_t *p;
+    uint64_t n;
+    __device__ uint32_t operator()(uint64_t i) const { return i < n ? p[i] : 0u; }
+};
+struct CntU64In {
+    const uint32_t *p;
+    uint64_t n;
+    __device__ uint64_t operator()(uint64_t i) const { return i < n ? (uint64_t)p[i] : 0ull; }
+};
+struct RowPtrOfUnits {
+    const uint32_t *unit_first, *tile_base;
+    uint32_t *c_rowptr;
+    __device__ void operator()(uint64_t i) const { c_rowptr[i] = tile_base[unit_first[i]]; }
+};
+struct COfWaveW {
+    const uint32_t *task_begin;
+    uint32_t c_size;
+    uint32_t *out;
+    __device__ void operator()(uint64_t w) const
+    {
+        const uint32_t t = (uint32_t)(w * 64);
+        uint32_t lo = 0, hi = c_size - 1u;  // last c with task_begin[c] <= t
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (task_begin[mid] <= t) lo = mid;
+            else hi = mid - 1u;
+        }
+        out[w] = lo;
+    }
+};
+struct SetOne64 {
+    uint64_t *p;
+    uint64_t v;
+    __device__ void operator()(uint64_t) const { *p = v; }
+};
+struct SetOne32 {
+    uint32_t *p;
+    uint32_t v;
+    __device__ void operator()(uint64_t) const { *p = v; }
+};
+
+}  // namespace
+
+// true: C->keys / bmps / offsets / nnz / rowptr / block_num are set; tasks = the surviving pairs ((A tile << 32) | B tile) grouped by C
+// tile in C's key order, inside a tile in ascending A tile; task_begin[c] = first task of C tile c (c_size + 1 entries); c_of_wave[w] =
+// C tile of task 64 w -- what rowmerge_tasklist and the pipeline's T_3 .. T_9 produce.  false: not applicable (B wider than
+// kWinMaxPerRow windows, or too much scratch); nothing of C was allocated.
+bool rowmerge_windowed(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, DevBuf<uint64_t> &tasks,
+                       DevBuf<uint32_t> &task_begin, DevBuf<uint32_t> &c_of_wave, uint64_t *n_tasks_out, hipStream_t st)
+{
+    const uint64_t rows = (uint64_t)A->num_block_rows();
+    const uint64_t ncols64 = (uint64_t)B->num_block_cols();
+    if (rows == 0 || rows >= (1ull << 31) || total == 0 || total >= (1ull << 32)) return false;
+    const char *wm = getenv("BMSP_WIN_MAX");  // experiment switch: most windows that tile B's block columns
+    const uint64_t max_per_row = wm ? (uint64_t)atoll(wm) : (uint64_t)kWinMaxPerRow;
+    if (ncols64 == 0 || ncols64 > max_per_row * (uint64_t)kWinSlots) return false;
+    const uint32_t ncols = (uint32_t)ncols64;
+    const char *ce = getenv("BMSP_WIN_CAND");  // experiment / test switch: candidate pairs per window a block-row is cut for
+    const uint32_t cw = ce ? (uint32_t)std::max(1, atoi(ce)) : kWinCand;
+    ensure_rowptr(A, st);
+    ensure_rowptr(B, st);
+    ensure_sym_recs(B, st);
+    ensure_col_index(B, kWinGran, st);
+    const RowCand rc{first_pos, A->rowptr};
+    DevBuf<uint32_t> unit_first(rows + 1);
+    DevBuf<uint64_t> scr_first(rows + 1);
+    HostScalar<uint32_t> n_units_h;
+    HostScalar<uint64_t> n_scr_h;
+    device_exclusive_scan<uint32_t>(PlanUnitsIn{rc, rows, ncols, cw}, PtrOutTotal<uint32_t>{unit_first.p, rows, n_units_h.dev()}, rows + 1, st);
+    device_exclusive_scan<uint64_t>(PlanScratchIn{rc, rows, ncols}, PtrOutTotal<uint64_t>{scr_first.p, rows, n_scr_h.dev()}, rows + 1, st);
+    const uint32_t U = n_units_h.wait(st);
+    const uint64_t S = n_scr_h.wait(st);
+    if (U == 0 || U >= (1u << 31) || S >= (1ull << 32) || S * 16 > (24ull << 30)) return false;
+    DevBuf<WinUnit> units(U);
+    device_for_each(EmitUnits{rc, ncols, cw, unit_first.p, scr_first.p, units.p}, rows, st);
+    DevBuf<uint32_t> t_col(S), t_cnt(S), u_tiles((size_t)U + 1), u_surv((size_t)U + 1), u_nnz((size_t)U + 1);
+    DevBuf<uint64_t> t_bmp(S);
+    DevBuf<uint32_t> a_join(4 * (size_t)A->block_num);
+    device_for_each(JoinA{A->keys, B->rowptr, B->col_index_row, (uint32_t)B->num_block_rows(), a_join.p}, (uint64_t)A->block_num, st);
+    WinArgs g{};
+    g.a_join = a_join.p;
+    g.a_keys = A->keys; g.a_bmps = A->bmps; g.a_rowptr = A->rowptr;
+    g.b_keys = B->keys; g.b_bmps = B->bmps; g.b_recs = B->sym_recs; g.b_rowptr = B->rowptr; g.b_idx_row = B->col_index_row; g.b_idx = B->col_index; g.b_block_rows = (uint32_t)B->num_block_rows();
+    g.units = units.p; g.n_units = U;
+    g.t_col = t_col.p; g.t_cnt = t_cnt.p; g.t_bmp = t_bmp.p; g.u_tiles = u_tiles.p; g.u_surv = u_surv.p; g.u_nnz = u_nnz.p;
+    hipLaunchKernelGGL(rowwin_count_kernel<kWinSlots>, dim3(U), dim3(kWinThreads), 0, st, g, ncols);
+    BMSP_CHECK_LAUNCH();
+    DevBuf<uint32_t> tile_base((size_t)U + 1), task_base((size_t)U + 1);
+    DevBuf<uint64_t> val_base((size_t)U + 1);
+    HostScalar<uint32_t> c_size_h, n_tasks_h;
+    HostScalar<uint64_t> nnz_h;
+    device_exclusive_scan<uint32_t>(CntU32In{u_tiles.p, U}, PtrOutTotal<uint32_t>{tile_base.p, U, c_size_h.dev()}, (uint64_t)U + 1, st);
+    device_exclusive_scan<uint32_t>(CntU32In{u_surv.p, U}, PtrOutTotal<uint32_t>{task_base.p, U, n_tasks_h.dev()}, (uint64_t)U + 1, st);
+    device_exclusive_scan<uint64_t>(CntU64In{u_nnz.p, U}, PtrOutTotal<uint64_t>{val_base.p, U, nnz_h.dev()}, (uint64_t)U + 1, st);
+    const uint32_t c_size = c_size_h.wait(st), n_tasks = n_tasks_h.wait(st);
+    const uint64_t c_nnz = nnz_h.wait(st);
+    C->block_num = c_size;
+    C->rowptr = (uint32_t *)pool_alloc(sizeof(uint32_t) * (size_t)(rows + 1));
+    C->rowptr_rows = (int64_t)rows;
+    C->max_row_blocks = -1;  // (ensure_row_stats looks when somebody asks)
+    C->keys = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
+    C->bmps = (uint64_t *)pool_alloc(8 * (size_t)(c_size ? c_size : 1));
+    C->offsets = (uint64_t *)pool_alloc(8 * ((size_t)c_size + 1));
+    C->nnz = (int64_t)c_nnz;
+    device_for_each(RowPtrOfUnits{unit_first.p, tile_base.p, C->rowptr}, rows + 1, st);
+    device_for_each(SetOne64{C->offsets + c_size, c_nnz}, 1, st);
+    tasks.alloc(n_tasks);
+    task_begin.alloc((size_t)c_size + 1);
+    c_of_wave.alloc((size_t)n_tasks / 64 + 1);
+    *n_tasks_out = n_tasks;
+    device_for_each(SetOne32{task_begin.p + c_size, n_tasks}, 1, st);
+    if (c_size) {
+        g.tile_base = tile_base.p; g.task_base = task_base.p; g.val_base = val_base.p;
+        g.c_keys = C->keys; g.c_bmps = C->bmps; g.c_offs = C->offsets; g.task_begin = task_begin.p; g.tasks = tasks.p;
+        hipLaunchKernelGGL(rowwin_fill_kernel<kWinSlots>, dim3(U), dim3(kWinThreads), 0, st, g, ncols);
+        BMSP_CHECK_LAUNCH();
+        device_for_each(COfWaveW{task_begin.p, c_size, c_of_wave.p}, ((uint64_t)n_tasks + 63) / 64, st);
+    }
+    return true;
+}
+
+}  // namespace bmsp

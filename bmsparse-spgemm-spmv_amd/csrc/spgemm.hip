@@ -1073,7 +1073,10 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         // summation order on v_mfma_f32_16x16x4_f32: any tc_version, as fp32 operands always take V15's numerics)
         const bool rm_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || (A->dtype == BMSP_F32 && !getenv("BMSP_MAC_VALU_DENSE") && !getenv("BMSP_MAC_F32MFMA"));
         const char *sf = getenv("BMSP_MAC_STRIP");
-        const bool strip_allowed = rm_numeric && !rm_no_strip && !(sf && sf[0] == '0');
+        // BMSP_SPGEMM_ROWWINDOW=0: never the column-window passes (rowwindow.hip); =1: always, whatever the operands look like (tests)
+        const char *we = getenv("BMSP_SPGEMM_ROWWINDOW");
+        const bool win_off = we && we[0] == '0', win_force = we && we[0] == '1';
+        const bool strip_allowed = rm_numeric && !rm_no_strip && !(sf && sf[0] == '0') && !win_force;
         // strip mode done: value array, numeric stage (or zero values for bmsp_spgemm_symbolic), statistics
         auto finish_strip = [&](uint64_t surv) {
             tm.mark(3);
@@ -1120,7 +1123,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         }
         run_t2();
         const bool rm_on = !rm_off && total && (mode == BMSP_SORT_AUTO || rm_force);
-        bool try_strip = rm_on && strip_allowed && !strip_tried && hint != 2 && hint != 3;
+        bool try_strip = rm_on && strip_allowed && !strip_tried && hint != 2 && hint != 3 && hint != 4;
         if (try_strip) try_strip = mac_strip_operands_ok(A, B, st);
         if (try_strip) {
             uint64_t surv = 0, cand = 0;
@@ -1135,15 +1138,20 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
             tm.mark(-1);
         }
         if (rm_on && hint != 3) {
-            if (rowmerge_tasklist(A, B, C.get(), first_pos.p, total, rm_tasks, task_begin, c_of_wave, &n_tasks, st)) {
-                remember(2);
+            // task-list mode (a wave per block-row, hash table of ~900 C tiles); operands with hub block-rows: column windows (a workgroup
+            // per block-row and window of block columns, dense tables: rowwindow.hip); neither applies: the pipeline
+            int got = 0;
+            if (hint != 4 && !win_force && rowmerge_tasklist(A, B, C.get(), first_pos.p, total, rm_tasks, task_begin, c_of_wave, &n_tasks, st)) got = 2;
+            else if (!win_off && rowmerge_windowed(A, B, C.get(), first_pos.p, total, rm_tasks, task_begin, c_of_wave, &n_tasks, st)) got = 4;
+            if (got) {
+                remember(got);
                 have_tasks = true;
                 tasks_sorted = rm_tasks.p;
                 c_size = (uint32_t)C->block_num;
                 tm.mark(3);
                 S->surviving_tasks = (int64_t)n_tasks;
                 S->bmp_reduction = (int64_t)(total - n_tasks);
-                S->sort_path = BMSP_SORT_PATH_ROWMERGE;
+                S->sort_path = got == 2 ? BMSP_SORT_PATH_ROWMERGE : BMSP_SORT_PATH_ROWWINDOW;
                 finish_structure();
                 tm.mark(9);
             } else {

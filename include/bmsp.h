@@ -197,6 +197,7 @@ typedef struct {
 } bmsp_spgemm_stats;
 /* implementations behind one tc_version (the launcher picks by the product's shape; all give the tc_version's numerics) */
 #define BMSP_SORT_PATH_ROWMERGE 2
+#define BMSP_SORT_PATH_ROWWINDOW 3 /* none either: block-rows of C formed window by window of block columns in dense LDS tables (operands with hub block-rows) */
 #define BMSP_MAC_DEFAULT 0 /* the only kernel of that tc_version (V15 vector-ALU kernels, K = 16 MFMA kernels) */
 #define BMSP_MAC_STAGED 1  /* tc 4: K = 32 MFMA, operands staged through LDS per task (sparse task lists) */
 #define BMSP_MAC_DIRECT 2  /* tc 4: K = 32 MFMA, operand lines loaded per task straight into the MFMA lanes */
@@ -250,6 +251,10 @@ int bmsp_selftest_mfma_layout(int *mismatches);
  * block-MAC on the matrix cores with values bit-identical to the vector-ALU kernel (BMSP_MAC_F32MFMA=1 selects that kernel; it is not the
  * default: measured on MI355X it is bound by the 256-byte operand tiles it reads and no faster than the vector-ALU kernels). */
 int bmsp_selftest_mfma_f32_chain(int *mismatches);
+/* Hardware self test of the byte-permute form of bmp_calculator (src/bmSparse_SPGEMM.cu:787-810) the row-merge passes use: 2^20 pairs of
+ * bitmaps of every density, the v_perm_b32 sign-replication product on the row-major copy of B's tile against the multiply form on the
+ * tile as stored.  *mismatches = pairs whose products differ (0 on gfx950). */
+int bmsp_selftest_tile_product(int *mismatches);
 
 /* bb_segsort<K,T>(keys, vals, n, segs, length)  -- include/bb_segsort-master/bb_segsort.h:35-192,
  * instantiated by the reference with K = uint64_t, T = 16-byte task_list_elem (src/bmSparse_SPGEMM.cu:1010).

@@ -26,6 +26,12 @@ int main()
         uint64_t e = brute_product(a, b);
         if (bmsp::tile_product_bmp(a, b) != e) { std::printf("FAIL product %016llx %016llx\n", (unsigned long long)a, (unsigned long long)b); return 1; }
         if (bmsp::tile_product_empty(a, b) != (e == 0)) { std::printf("FAIL empty\n"); return 1; }
+        if (bmsp::tile_product_rm(a, bmsp::tile_transpose(b)) != e) { std::printf("FAIL row-major product\n"); return 1; }
+        if (bmsp::tile_transpose(bmsp::tile_transpose(a)) != a) { std::printf("FAIL transpose\n"); return 1; }
+        for (int q = 0; q < 4; q++) {  // transpose: position 8r + c <-> 8c + r
+            const int r = (int)(rng() % 8), c = (int)(rng() % 8);
+            if (bmsp::tile_has(bmsp::tile_transpose(a), 8 * c + r) != bmsp::tile_has(a, 8 * r + c)) { std::printf("FAIL transpose bit\n"); return 1; }
+        }
         int p = (int)(rng() % 64);
         int rank = 0;
         for (int q = 0; q < p; q++) rank += (int)((a >> (63 - q)) & 1);

@@ -452,6 +452,15 @@ def test_mfma_16x16x32_lane_layout(bmsp):
     assert bad.value == 0
 
 
+def test_tile_product_byte_permute_form(bmsp):
+    """the v_perm_b32 form of the 8x8 boolean tile product (bmp_calculator) used by the column-window passes, against the multiply form,
+    on the hardware: the selector semantics (8..11 = sign of the odd bytes) are an ISA detail worth pinning."""
+    import ctypes
+    bad = ctypes.c_int(-1)
+    bmsp.check(bmsp.lib().bmsp_selftest_tile_product(ctypes.byref(bad)))
+    assert bad.value == 0
+
+
 def test_segmented_task_sort_wide_words(oracle, bmsp, monkeypatch):
     """the register segment sort with 64-bit sort words (products whose C has more than 2^20 block columns use them; forced here):
     segments of every size class (2 .. 64 words per lane would need > 2048 tasks per block-row: the rmat case reaches the 16 / 32
@@ -719,7 +728,7 @@ def test_spgemm_rowmerge_path(oracle, bmsp, monkeypatch, case, dtype):
     """BMSP_SPGEMM_ROWMERGE=1: C's structure formed block-row by block-row in LDS (rowmerge.hip: hash of the surviving pairs' columns, OR of
     the tile-product bitmaps, rank by column) instead of expand - sort - compress.  Stage counters, keys, bitmaps and offsets are the
     oracle's bit for bit; the values are the strip kernel's, hence bit-identical with the pipeline + strip kernel on the same operands.  A
-    block-row of C beyond the pass's capacity (rmat_hub) must fall back to the pipeline.  dtype 0: fp32 operands, the strip kernel on
+    block-row of C beyond the pass's capacity (rmat_hub) goes to the column-window passes (test_spgemm_rowwindow_path).  dtype 0: fp32 operands, the strip kernel on
     v_mfma_f32_16x16x4_f32 -- V15's summation order, so the values are the oracle's (and the vector-ALU kernel's) bit for bit."""
     from pybmsp import gen
     exact = False
@@ -742,7 +751,7 @@ def test_spgemm_rowmerge_path(oracle, bmsp, monkeypatch, case, dtype):
     monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "1")
     st = check_spgemm(oracle, bmsp, A, Bc, dtype, 0, tc, exact_expected=exact)
     if case == "rmat_hub":
-        assert st["sort_path"] != 2, st
+        assert st["sort_path"] == 3, st  # round 4: hub block-rows take the column-window passes (rowwindow.hip), not the pipeline
         return
     assert st["sort_path"] == 2 and (st["c_blocks"] == 0 or (st["mac_variant"] == 3 and st["mac_kernel"] == tc)), st
     a = bmsp.BmSpMatrix.from_coo(*A, dtype=dtype)
@@ -790,6 +799,82 @@ def test_spgemm_rowmerge_task_list(oracle, bmsp, monkeypatch, case, dtype, tc):
     monkeypatch.setenv("BMSP_MAC_STRIP", "0")
     old, sto = bmsp.spgemm(a, b, tc_version=tc)
     assert sto["sort_path"] in (0, 1) and sto["mac_variant"] == stn["mac_variant"]
+    for x, y, z in zip(old.host_arrays(), new.host_arrays(), new2.host_arrays()):
+        np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(x, z)
+
+
+@pytest.mark.parametrize("case", ["rmat13", "rmat11_narrow", "hub_row_diag", "hub_rmat", "rect_wide", "long_a_rows", "filtered", "cage", "empty"])
+@pytest.mark.parametrize("dtype,tc", [(0, 5), (1, 4), (1, 5), (2, 5)])
+def test_spgemm_rowwindow_path(oracle, bmsp, monkeypatch, case, dtype, tc):
+    """Column-window passes (rowwindow.hip; round 4): a workgroup per (block-row of A, window of C's block columns), dense tables in LDS,
+    the order of a C tile's tasks from 64-bit hit masks over rounds of 64 A tiles.  Taken by the library for operands with hub block-rows
+    (rmat13: the row-merge task-list pass refuses them); forced here for the other shapes (BMSP_SPGEMM_ROWWINDOW=1) and with small windows
+    (BMSP_WIN_CAND) so that small inputs cross every boundary: several windows per block-row, windows that hold no tile, block-rows of A of
+    more than 64 tiles (several rounds), a block-row whose candidates all die in the filter, B wider than one window.  Stage counters,
+    keys, bitmaps, offsets: the oracle's bit for bit; every array of C: the pipeline's bit for bit (task order = summation order)."""
+    from pybmsp import gen
+    exact = False
+    force, cand = True, None
+    if case == "rmat13":      # what the library picks by itself
+        n, _, r, c, v = gen.rmat(13, 16)
+        A = Bc = (n, n, r, c, np.round(v * 8) / 8)
+        force = False
+    elif case == "rmat11_narrow":  # 64-column windows: 4 per block-row, most of them nearly empty
+        n, _, r, c, v = gen.rmat(11, 8)
+        A = Bc = (n, n, r, c, np.round(v * 8) / 8)
+        cand = 64
+    elif case in ("hub_row_diag", "hub_rmat"):
+        n, r, c, v = _hub_matrix(gen, "diag" if case == "hub_row_diag" else "rmat")
+        A = Bc = (n, n, r, c, np.round(np.asarray(v, dtype=np.float64) * 16) / 16)
+        cand = 512
+    elif case == "rect_wide":  # B has 2400 block columns: two windows by the table size alone; ragged edges
+        rng = np.random.default_rng(7)
+        m, k, nn = 300, 411, 19195
+        ra, ca = rng.integers(0, m, 4000), rng.integers(0, k, 4000)
+        rb, cb = rng.integers(0, k, 30000), rng.integers(0, nn, 30000)
+        A = (m, k, ra, ca, rng.integers(1, 5, 4000).astype(np.float64))
+        Bc = (k, nn, rb, cb, rng.integers(1, 5, 30000).astype(np.float64))
+        exact = True
+    elif case == "long_a_rows":  # block-rows of A of ~200 tiles: four rounds of 64, tasks of one C tile spread over them
+        rng = np.random.default_rng(11)
+        m, k = 64, 1600
+        ra = rng.integers(0, m, 20000); ca = rng.integers(0, k, 20000)
+        rb = np.repeat(np.arange(k), 6); cb = (rb * 7 + np.tile(np.arange(6), k) * 5) % 300
+        A = (m, k, ra, ca, rng.integers(1, 4, 20000).astype(np.float64))
+        Bc = (k, 300, rb, cb, np.ones(rb.size))
+        exact = True
+        cand = 2048
+    elif case == "filtered":
+        n = 2048
+        ra = np.arange(n); ca = (ra // 8) * 8
+        rb = (np.arange(n) // 8) * 8 + 7; cb = np.arange(n)
+        A, Bc, exact = (n, n, ra, ca, np.ones(n)), (n, n, rb, cb, np.ones(n)), True
+    elif case == "cage":
+        n, _, r, c, v = gen.cage_like(20000, per_row=6.0)
+        A = Bc = (n, n, r, c, np.round(v * 64) / 64)
+        cand = 256
+    else:  # empty: A has block-rows without a tile and tiles whose block column has no block-row in B
+        A = (100, 64, np.array([0, 3, 90, 91]), np.array([1, 60, 2, 63]), np.array([1.0, 2.0, 3.0, 4.0]))
+        Bc = (64, 40, np.array([1, 2, 2]), np.array([0, 39, 17]), np.array([1.0, 1.0, 2.0]))
+        exact = True
+    if force:
+        monkeypatch.setenv("BMSP_SPGEMM_ROWWINDOW", "1")
+    if cand:
+        monkeypatch.setenv("BMSP_WIN_CAND", str(cand))
+    st = check_spgemm(oracle, bmsp, A, Bc, dtype, 0, tc, exact_expected=exact)
+    assert st["sort_path"] == 3, st
+    a = bmsp.BmSpMatrix.from_coo(*A, dtype=dtype)
+    b = bmsp.BmSpMatrix.from_coo(*Bc, transposed=True, dtype=dtype)
+    new, stn = bmsp.spgemm(a, b, tc_version=tc)
+    new2, stn2 = bmsp.spgemm(a, b, tc_version=tc)  # (remembered on the handle: straight to the window passes)
+    assert stn["sort_path"] == 3 and stn2["sort_path"] == 3
+    monkeypatch.setenv("BMSP_SPGEMM_ROWWINDOW", "0")
+    monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "0")
+    old, sto = bmsp.spgemm(a, b, tc_version=tc)
+    assert sto["sort_path"] in (0, 1) and sto["mac_variant"] == stn["mac_variant"]
+    for key in ("task_list_size", "bmp_reduction", "surviving_tasks", "c_blocks", "c_nnz"):
+        assert stn[key] == sto[key], key
     for x, y, z in zip(old.host_arrays(), new.host_arrays(), new2.host_arrays()):
         np.testing.assert_array_equal(x, y)
         np.testing.assert_array_equal(x, z)

@@ -7,12 +7,13 @@ import numpy as np, pybmsp as B
 from pybmsp import gen
 cases = [("fem_like(47,27pt)", lambda: gen.fem_like(47, "27pt")), ("cage_like(130228)", lambda: gen.cage_like(130228)),
          ("dense banded(131072,32)", lambda: gen.banded(131072, 32)), ("banded(101492,8)", lambda: gen.banded(101492, 8)),
-         ("rmat16(16,8)", lambda: gen.rmat(16, 8)), ("ceiling banded(147456,256)", lambda: gen.banded(147456, 256))]
+         ("rmat16(16,8)", lambda: gen.rmat(16, 8)), ("ceiling banded(147456,256)", lambda: gen.banded(147456, 256)),
+         ("rmat22(22,1)", lambda: gen.rmat(22, 1)), ("rmat20(20,2)", lambda: gen.rmat(20, 2))]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 quick = "--quick" in sys.argv
 fp32 = "--fp32" in sys.argv  # with --quick: the fp32 V15 configuration instead of the fp16 MFMA one
 half5 = "--half5" in sys.argv  # with --quick: fp16 operands with V15 numerics (tc_version 5: the reference's default configuration)
-cases = [c for c in cases if args[0] in c[0]] if args else cases[:-1]
+cases = [c for c in cases if args[0] in c[0]] if args else cases[:5]
 for name, mk in cases:
     n, _, r, c, v = mk()
     for dtype, tc in ((((B.F32, 5),) if fp32 else ((B.F16, 5),) if half5 else ((B.F16, 4),)) if quick else ((B.F32, 5), (B.F16, 5), (B.F16, 4))):
