@@ -397,6 +397,7 @@ void invalidate_matrix(bmsp_matrix_s *m, int structure_changed)
     m->values_finite = -1;
     if (!structure_changed) return;
     pool_free(m->rowptr); m->rowptr = nullptr; m->rowptr_rows = 0; m->max_row_blocks = -1;
+    m->struct_hash = 0; m->sp_a_hash = 0; m->sp_b_hash = 0;
     m->rm_partner_keys = nullptr; m->rm_partner_blocks = 0; m->rm_partner_mode = 0;
     pool_free(m->sp_tasks); pool_free(m->sp_task_begin); pool_free(m->sp_c_of_wave);
     m->sp_tasks = nullptr; m->sp_task_begin = nullptr; m->sp_c_of_wave = nullptr; m->sp_n_tasks = 0;
@@ -436,6 +437,38 @@ void ensure_row_stats(bmsp_matrix_s *m, hipStream_t st)
     BMSP_HIP(hipMemsetAsync(mx.p, 0, 8, st));
     device_max_sum(RowBlocksIn{m->rowptr}, (uint64_t)nbr, mx.p, (unsigned long long *)nullptr, st);
     m->max_row_blocks = (int64_t)read_back(mx.p, st);
+}
+
+namespace {
+struct StructMix {
+    const uint64_t *keys, *bmps;
+    __device__ uint64_t operator()(uint64_t b) const
+    {
+        uint64_t z = keys[b] * 0x9E3779B97F4A7C15ull ^ bmps[b];
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+};
+}  // namespace
+
+// Fingerprint of a matrix's STRUCTURE (dimensions, layout, keys, bitmaps): one reduction the first time, cached on the handle, dropped by
+// bmsp_matrix_invalidate(m, 1).  A product stamps C with its operands' fingerprints (spgemm); bmsp_spgemm_numeric compares them.
+uint64_t ensure_struct_hash(bmsp_matrix_s *m, hipStream_t st)
+{
+    if (m->struct_hash) return m->struct_hash;
+    unsigned long long sum = 0;
+    if (m->block_num) {
+        DevBuf<unsigned long long> acc(1);
+        BMSP_HIP(hipMemsetAsync(acc.p, 0, 8, st));
+        device_max_sum(StructMix{m->keys, m->bmps}, (uint64_t)m->block_num, (unsigned long long *)nullptr, acc.p, st);
+        sum = read_back(acc.p, st);
+    }
+    uint64_t h = sum ^ ((uint64_t)(uint32_t)m->num_rows << 32 | (uint64_t)(uint32_t)m->num_cols) * 0xD6E8FEB86659FD93ull ^ (uint64_t)m->block_num * 0xA24BAED4963EE407ull ^
+                 (uint64_t)(m->transposed ? 0x5851F42D4C957F2Dull : 0);
+    if (h == 0) h = 1;
+    m->struct_hash = h;
+    return h;
 }
 
 namespace {
@@ -585,6 +618,7 @@ void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st)
     if (m->dtype == BMSP_F32 && m->block_num < (1ll << 24) && mac_f32_mfma_usable(st)) ensure_lane_tiles(m, st);
     // what decides whether a product takes the row-merge path: block-row pointer and maxima, "every stored value is finite"
     ensure_row_stats(m, st);
+    if (m->ownership != 2 || !m->view_block_begin) ensure_struct_hash(m, st);
     if (m->dtype != BMSP_F64) ensure_finite_flag(m, st);
 }
 

@@ -54,6 +54,10 @@ struct bmsp_matrix_s {
     uint32_t *sp_task_begin = nullptr, *sp_c_of_wave = nullptr;
     uint64_t sp_n_tasks = 0, sp_candidates = 0;
     int64_t sp_a_blocks = 0, sp_b_blocks = 0;
+    // a product remembers which operand STRUCTURES it was formed from (struct_hash of A and B; 0 = not stamped: a view, adopted arrays): the
+    // fast paths of bmsp_spgemm_numeric trust C only when the stamps match the operands it is given
+    uint64_t sp_a_hash = 0, sp_b_hash = 0;
+    uint64_t struct_hash = 0;  // this matrix: sum over its blocks of mix(key, bitmap), + dimensions; 0 = not computed (ensure_struct_hash)
     int values_finite = -1;
     int f32_exp_min = 255, f32_exp_max = 0;  // fp32: biased exponent range of the non-zero stored values (with values_finite)       // fp16 operands of the strip block-MAC: 1 = no inf / NaN stored (-1 = not looked yet)
     // a row-panel view points into its parent
@@ -112,6 +116,7 @@ bmsp_matrix_s *build_from_device_coo(int num_rows, int num_cols, int64_t nnz, co
 
 void ensure_rowptr(bmsp_matrix_s *m, hipStream_t st);
 void ensure_row_stats(bmsp_matrix_s *m, hipStream_t st);
+uint64_t ensure_struct_hash(bmsp_matrix_s *m, hipStream_t st);
 void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st);
 void ensure_sym_recs(bmsp_matrix_s *m, hipStream_t st);
 void ensure_col_index(bmsp_matrix_s *m, uint32_t gran, hipStream_t st);

@@ -18,6 +18,8 @@
 #include "matrix.h"
 #include "prims.hip.h"
 #include "bmsp_bits.h"
+#include <algorithm>
+#include <vector>
 
 namespace bmsp {
 namespace {
@@ -108,9 +110,13 @@ struct WinArgs {
     uint64_t *c_keys, *c_bmps, *c_offs;
     uint32_t *task_begin;
     uint64_t *tasks;
+    unsigned long long *prof;  // BMSP_WIN_PROF=1: per window {clocks of the count pass, of its look-ups, clocks of the fill pass, of its look-ups}
 };
 
-constexpr int kWinWaves = 8;                    // waves per workgroup
+#ifndef BMSP_WIN_WAVES
+#define BMSP_WIN_WAVES 8
+#endif
+constexpr int kWinWaves = BMSP_WIN_WAVES;       // waves per workgroup
 constexpr int kWinThreads = 64 * kWinWaves;
 constexpr int kWinTiles = 64 / kWinWaves;       // A tiles of a round (64) a wave looks up; their lanes (64 / kWinTiles each) work together
 constexpr int kWinLanes = 64 / kWinTiles;
@@ -170,14 +176,22 @@ __device__ __forceinline__ void round_prologue(const WinArgs &g, const WinUnit &
             if (cut_lo) s0 = g.b_idx[off + u.lo / kWinGran];
             if (cut_hi) s1 = g.b_idx[off + u.hi / kWinGran];
         }
-        // short block-rows: every lane of the group looks at two tiles; tiles below an edge = where the edge cuts
+        // short block-rows: the lanes of the group look at all of its tiles together; tiles below an edge = where the edge cuts
         const bool small = off == ~0u && be > bb;
-        uint32_t c0 = ~0u, c1 = ~0u;
-        if (small && bb + sub < be) c0 = key_col(g.b_keys[bb + sub]);
-        if (small && bb + (uint32_t)kWinLanes + sub < be) c1 = key_col(g.b_keys[bb + (uint32_t)kWinLanes + sub]);
+        constexpr int kProbes = ((int)kIdxMinLen + kWinLanes - 1) / kWinLanes;
+        uint32_t c[kProbes];
+#pragma unroll
+        for (int p = 0; p < kProbes; p++) {
+            c[p] = ~0u;
+            if (small && bb + (uint32_t)(p * kWinLanes) + sub < be) c[p] = key_col(g.b_keys[bb + (uint32_t)(p * kWinLanes) + sub]);
+        }
         const uint64_t gm = (1ull << kWinLanes) - 1ull;
-        const uint32_t below_lo = (uint32_t)__popcll((__ballot(c0 < u.lo) >> shift) & gm) + (uint32_t)__popcll((__ballot(c1 < u.lo) >> shift) & gm);
-        const uint32_t below_hi = (uint32_t)__popcll((__ballot(c0 < u.hi) >> shift) & gm) + (uint32_t)__popcll((__ballot(c1 < u.hi) >> shift) & gm);
+        uint32_t below_lo = 0, below_hi = 0;
+#pragma unroll
+        for (int p = 0; p < kProbes; p++) {
+            below_lo += (uint32_t)__popcll((__ballot(c[p] < u.lo) >> shift) & gm);
+            below_hi += (uint32_t)__popcll((__ballot(c[p] < u.hi) >> shift) & gm);
+        }
         if (small) { s0 = bb + below_lo; s1 = bb + below_hi; }
     } else {
         s0 = u.lo ? lower_bound_col_group(g.b_keys, bb, be, u.lo, sub, shift) : bb;
@@ -282,9 +296,13 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_count_kernel(WinArgs g, ui
     for (int s = threadIdx.x; s < T; s += kWinThreads) { cnt[s] = 0u; bmp[s] = 0ull; }
     const uint32_t a0 = g.a_rowptr[u.row], a1 = g.a_rowptr[u.row + 1];
     const u32x4w *recs = (const u32x4w *)g.b_recs;
+    const unsigned long long clk0 = g.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long clk_look = 0;
     for (uint32_t r0 = a0, par = 0; r0 < a1; r0 += 64u, par ^= 1u) {
+        const unsigned long long c0 = g.prof ? __builtin_amdgcn_s_memtime() : 0ull;
         round_prologue(g, u, ncols_all, rt[par], r0, a1, w, lane);
         __syncthreads();  // (also orders the table's zeroing before the first update; the other round table is free again: every wave has its copy)
+        if (g.prof) clk_look += __builtin_amdgcn_s_memtime() - c0;
         const RoundRegs q = round_regs(rt[par], lane);
         for (uint32_t i0 = (uint32_t)w; i0 < q.S; i0 += (uint32_t)(kWinWaves * kWinBatchCount)) {
             StepScalars t[kWinBatchCount];
@@ -337,6 +355,7 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_count_kernel(WinArgs g, ui
         g.u_tiles[unit] = tiles;
         g.u_surv[unit] = s1;
         g.u_nnz[unit] = s2;
+        if (g.prof) { g.prof[4 * unit] = __builtin_amdgcn_s_memtime() - clk0; g.prof[4 * unit + 1] = clk_look; }
     }
 }
 
@@ -389,9 +408,13 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g, uin
     }
     const uint32_t a0 = g.a_rowptr[u.row], a1 = g.a_rowptr[u.row + 1];
     const u32x2w *recs = (const u32x2w *)g.b_recs;  // {block column, rows the tile uses} = the upper half of a record
+    const unsigned long long clk0 = g.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long clk_look = 0;
     for (uint32_t r0 = a0, par = 0; r0 < a1; r0 += 64u, par ^= 1u) {
+        const unsigned long long c0 = g.prof ? __builtin_amdgcn_s_memtime() : 0ull;
         round_prologue(g, u, ncols_all, rt[par], r0, a1, w, lane);
         __syncthreads();  // the round's look-ups are in; the previous round's second half is over (and C's arrays / `begin` are written)
+        if (g.prof) clk_look += __builtin_amdgcn_s_memtime() - c0;
         const RoundRegs q = round_regs(rt[par], lane);
         uint64_t *const hit = hit2[par];
         // the previous round's marks become task slots taken, while this round's first records travel
@@ -451,6 +474,7 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g, uin
             for (int b = 0; b < kWinBatch; b++) place(t[b], r[b]);
         }
     }
+    if (g.prof && threadIdx.x == 0) { g.prof[4 * unit + 2] = __builtin_amdgcn_s_memtime() - clk0; g.prof[4 * unit + 3] = clk_look; }
 }
 
 struct JoinA {
@@ -556,6 +580,12 @@ bool rowmerge_windowed(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     g.b_keys = B->keys; g.b_bmps = B->bmps; g.b_recs = B->sym_recs; g.b_rowptr = B->rowptr; g.b_idx_row = B->col_index_row; g.b_idx = B->col_index; g.b_block_rows = (uint32_t)B->num_block_rows();
     g.units = units.p; g.n_units = U;
     g.t_col = t_col.p; g.t_cnt = t_cnt.p; g.t_bmp = t_bmp.p; g.u_tiles = u_tiles.p; g.u_surv = u_surv.p; g.u_nnz = u_nnz.p;
+    DevBuf<unsigned long long> prof;
+    if (getenv("BMSP_WIN_PROF")) {
+        prof.alloc(4 * (size_t)U);
+        BMSP_HIP(hipMemsetAsync(prof.p, 0, 32 * (size_t)U, st));
+        g.prof = prof.p;
+    }
     hipLaunchKernelGGL(rowwin_count_kernel<kWinSlots>, dim3(U), dim3(kWinThreads), 0, st, g, ncols);
     BMSP_CHECK_LAUNCH();
     DevBuf<uint32_t> tile_base((size_t)U + 1), task_base((size_t)U + 1);
@@ -588,6 +618,29 @@ bool rowmerge_windowed(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
         hipLaunchKernelGGL(rowwin_fill_kernel<kWinSlots>, dim3(U), dim3(kWinThreads), 0, st, g, ncols);
         BMSP_CHECK_LAUNCH();
         device_for_each(COfWaveW{task_begin.p, c_size, c_of_wave.p}, ((uint64_t)n_tasks + 63) / 64, st);
+    }
+    if (g.prof) {  // experiment: the slowest windows, with what they hold
+        std::vector<unsigned long long> hp(4 * (size_t)U);
+        std::vector<WinUnit> hu(U);
+        std::vector<uint32_t> hs(U), ht(U);
+        BMSP_HIP(hipMemcpyAsync(hp.data(), prof.p, 32 * (size_t)U, hipMemcpyDeviceToHost, st));
+        BMSP_HIP(hipMemcpyAsync(hu.data(), units.p, sizeof(WinUnit) * (size_t)U, hipMemcpyDeviceToHost, st));
+        BMSP_HIP(hipMemcpyAsync(hs.data(), u_surv.p, 4 * (size_t)U, hipMemcpyDeviceToHost, st));
+        BMSP_HIP(hipMemcpyAsync(ht.data(), u_tiles.p, 4 * (size_t)U, hipMemcpyDeviceToHost, st));
+        std::vector<uint32_t> rp(rows + 1);
+        BMSP_HIP(hipMemcpyAsync(rp.data(), A->rowptr, 4 * (rows + 1), hipMemcpyDeviceToHost, st));
+        BMSP_HIP(hipStreamSynchronize(st));
+        std::vector<uint32_t> order(U);
+        for (uint32_t i = 0; i < U; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hp[4 * a] + hp[4 * a + 2] > hp[4 * b] + hp[4 * b + 2]; });
+        unsigned long long tc = 0, tf = 0;
+        for (uint32_t i = 0; i < U; i++) { tc += hp[4 * i]; tf += hp[4 * i + 2]; }
+        fprintf(stderr, "[win prof] %u windows; clocks summed over windows: count %llu, fill %llu (s_memtime ticks)\n", U, tc, tf);
+        for (uint32_t i = 0; i < 12 && i < U; i++) {
+            const uint32_t q = order[i];
+            fprintf(stderr, "[win prof] row %6u cols [%5u,%5u) a_len %5u survivors %8u tiles %5u | count %9llu (look-ups %9llu) fill %9llu (look-ups %9llu)\n", hu[q].row, hu[q].lo,
+                    hu[q].hi, rp[hu[q].row + 1] - rp[hu[q].row], hs[q], ht[q], hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]);
+        }
     }
     return true;
 }

@@ -1047,6 +1047,9 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         }
         S->c_blocks = C->block_num;
         S->c_nnz = C->nnz;
+        // which structures this C is the product of (row-panel views are not stamped: bmsp_spgemm_numeric then checks the structure itself)
+        const bool a_view = A->ownership == 2 && (A->view_block_begin || A->view_values_end);
+        if (!a_view) { C->sp_a_hash = ensure_struct_hash(A, st); C->sp_b_hash = ensure_struct_hash(B, st); }
         *Cout = C.release();
     };
 
@@ -1322,7 +1325,13 @@ void spgemm_numeric(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc
     const bool mfma = tc_version != 5 && A->dtype == BMSP_F16;
     const bool strip_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || A->dtype == BMSP_F32;
     const char *sf = getenv("BMSP_MAC_STRIP");
-    if (C->block_num && strip_numeric && !(sf && sf[0] == '0') && mac_strip_operands_ok(A, B, st) && mac_strip_fits_c(C, st)) {
+    // The kernels below write C's values from the operands' structure and trust C to hold the product's: they run only for a C stamped
+    // with THESE operands' fingerprints (a product of bmsp_spgemm / _symbolic on operands of the same structure).  A stamped C of other
+    // operands is refused; an unstamped one (adopted arrays, a product of panel views) goes through the checked path at the end.
+    const bool stamped = C->sp_a_hash != 0 && C->sp_b_hash != 0;
+    if (stamped && (C->sp_a_hash != ensure_struct_hash(A, st) || C->sp_b_hash != ensure_struct_hash(B, st)))
+        fail(BMSP_ERR_INVALID, "C holds the structure of a product of other operands (its stamp does not match A and B)");
+    if (stamped && C->block_num && strip_numeric && !(sf && sf[0] == '0') && mac_strip_operands_ok(A, B, st) && mac_strip_fits_c(C, st)) {
         StageTimer tm(st, true);
         tm.mark(-1);
         launch_mac_strip(A, B, C, st);
@@ -1334,7 +1343,7 @@ void spgemm_numeric(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc
         S->c_blocks = C->block_num; S->c_nnz = C->nnz;
         return;
     }
-    if (C->block_num && C->sp_tasks && C->sp_a_blocks == A->block_num && C->sp_b_blocks == B->block_num) {
+    if (stamped && C->block_num && C->sp_tasks && C->sp_a_blocks == A->block_num && C->sp_b_blocks == B->block_num) {
         // C kept the product's sorted task list (bmsp_spgemm_symbolic): the block-MAC kernel of the tc_version runs from it
         StageTimer tm(st, true);
         tm.mark(-1);

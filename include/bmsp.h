@@ -230,12 +230,17 @@ int bmsp_spgemm(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, in
  *   bmsp_spgemm_symbolic: C's structure only; *C's values are allocated and zero; where the product was formed through a task list, C
  *                         keeps that list (8 bytes per surviving pair + 4 per C tile, freed with C).  Same arguments as bmsp_spgemm otherwise.
  *   bmsp_spgemm_numeric : C must hold the structure of A x B (from bmsp_spgemm / _symbolic on operands of the SAME structure); its values
- *                         are overwritten with those of A x B under tc_version's numerics -- exactly what bmsp_spgemm would store.  Where a
- *                         strip block-MAC applies (fp16 operands with tc_version 4, fp32 operands; block-rows of C of at most 256 tiles)
- *                         only that kernel runs; a C from bmsp_spgemm_symbolic that kept its task list runs the tc_version's block-MAC
- *                         kernel from it (any value type); otherwise (a C from bmsp_spgemm) the whole product runs, its structure is
- *                         checked against C's (BMSP_ERR_INVALID on a mismatch) and its values are copied.  After changing an operand's values in place call
- *                         bmsp_matrix_invalidate(m, 0) first (cached tile copies). */
+ *                         are overwritten with those of A x B under tc_version's numerics: for the V15 numerics (tc_version 5, and fp32 /
+ *                         fp64 operands under any tc_version) exactly what bmsp_spgemm would store, bit for bit; for the matrix-core
+ *                         kernels (fp16 operands, tc_version 1..4: exact products, fp32 accumulation in the order of whichever kernel
+ *                         runs) within the tolerance stated for them.  Every product is stamped with a fingerprint of its operands'
+ *                         structures (dimensions, keys, bitmaps): a C stamped for other operands is refused (BMSP_ERR_INVALID).  For a
+ *                         matching stamp: where a strip block-MAC applies (fp16 operands with tc_version 4, fp32 operands; block-rows of
+ *                         C of at most 256 tiles) only that kernel runs; a C from bmsp_spgemm_symbolic that kept its task list runs the
+ *                         tc_version's block-MAC kernel from it (any value type).  Otherwise -- no kept list, or a C without a stamp
+ *                         (adopted arrays) -- the whole product runs, its structure is checked against C's (BMSP_ERR_INVALID on a
+ *                         mismatch) and its values are copied.  After changing an operand's values in place call
+ *                         bmsp_matrix_invalidate(m, 0) first (cached tile copies); after changing its structure, (m, 1). */
 int bmsp_spgemm_symbolic(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, void *stream,
                          bmsp_spgemm_stats *stats);
 int bmsp_spgemm_numeric(bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t C, int tc_version, void *stream, bmsp_spgemm_stats *stats);

@@ -939,9 +939,12 @@ def test_spgemm_symbolic_numeric_split(oracle, bmsp, case, dtype, tc):
         n2, _, r2, c2, v2 = gen.banded(A[0], 3)
         other, _ = bmsp.spgemm(bmsp.BmSpMatrix.from_coo(n2, n2, r2, c2, v2, dtype=dtype), bmsp.BmSpMatrix.from_coo(n2, n2, r2, c2, v2, transposed=True, dtype=dtype),
                                tc_version=tc)
-        if dtype == 2 or (dtype == 1 and tc == 5):  # (the checked path; the strip kernels trust the caller, as the header says)
-            with pytest.raises(Exception):
-                bmsp.spgemm_numeric(a, b, other, tc_version=tc)
+        # every path refuses it: a product carries a fingerprint of its operands' structures (round 4; before, the strip kernels trusted the caller)
+        with pytest.raises(Exception):
+            bmsp.spgemm_numeric(a, b, other, tc_version=tc)
+        # ... and so is a C whose OPERANDS changed structure while C kept the old one
+        with pytest.raises(Exception):
+            bmsp.spgemm_numeric(bmsp.BmSpMatrix.from_coo(n2, n2, r2, c2, v2, dtype=dtype), bmsp.BmSpMatrix.from_coo(n2, n2, r2, c2, v2, transposed=True, dtype=dtype), sym, tc_version=tc)
 
 
 @pytest.mark.parametrize("seed", range(24))
