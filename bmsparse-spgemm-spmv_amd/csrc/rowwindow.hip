@@ -33,6 +33,8 @@ constexpr uint32_t kWinMaxPerRow = 16;    // widest operand taken: kWinMaxPerRow
 struct WinUnit {
     uint32_t row, lo, hi;  // block-row of A / C, block columns [lo, hi) of C
     uint32_t scr;          // first scratch slot of the window's tile list (hi - lo slots)
+    uint32_t a0, a1;       // the block-row's A tiles
+    uint32_t tab, stride;  // stretch table: entry (A tile a, this window's left edge) = tab + (a - a0) * stride; the right edge follows it
 };
 
 // windows of a block-row with `cand` candidate pairs over `ncols` block columns
@@ -70,11 +72,23 @@ struct PlanScratchIn {
     uint32_t ncols;
     __device__ uint64_t operator()(uint64_t i) const { return i < rows && rc(i) ? (uint64_t)ncols : 0ull; }  // the windows of a block-row tile its columns
 };
+// entries of the stretch table of a block-row: (window edges) x (A tiles)
+struct PlanTableIn {
+    RowCand rc;
+    uint64_t rows;
+    uint32_t ncols, cw;
+    __device__ uint64_t operator()(uint64_t i) const
+    {
+        if (i >= rows) return 0ull;
+        const uint32_t n = win_count(rc(i), ncols, cw);
+        return n ? (uint64_t)(n + 1u) * (uint64_t)(rc.a_rowptr[i + 1] - rc.a_rowptr[i]) : 0ull;
+    }
+};
 struct EmitUnits {
     RowCand rc;
     uint32_t ncols, cw;
     const uint32_t *unit_first;
-    const uint64_t *scr_first;
+    const uint64_t *scr_first, *tab_first;
     WinUnit *units;
     __device__ void operator()(uint64_t i) const
     {
@@ -84,14 +98,56 @@ struct EmitUnits {
         const uint32_t w = win_width(cand, ncols, cw), u0 = unit_first[i];
         for (uint32_t q = 0; q < n; q++) {
             const uint32_t lo = q * w, hi = lo + w < ncols ? lo + w : ncols;
-            units[u0 + q] = WinUnit{(uint32_t)i, lo, hi, (uint32_t)(scr_first[i] + lo)};
+            units[u0 + q] = WinUnit{(uint32_t)i, lo, hi, (uint32_t)(scr_first[i] + lo), rc.a_rowptr[i], rc.a_rowptr[i + 1], (uint32_t)tab_first[i] + q, n + 1u};
+        }
+    }
+};
+
+// The stretch table: for every A tile of a block-row and every window edge of that block-row, the first tile of B's block-row (the A
+// tile's column) at or beyond the edge.  One thread per A tile; long block-rows of B answer from their column index, short ones are
+// counted.  Built once per product: every window of the block-row, in both passes, then cuts B's block-rows with ONE load per A tile
+// (before: join record -> column index / keys, two dependent round trips per round and pass).
+struct BuildStretch {
+    RowCand rc;
+    uint32_t ncols, cw;
+    const uint64_t *a_keys, *b_keys;
+    const uint32_t *b_rowptr, *b_idx_row, *b_idx;
+    uint32_t b_block_rows;
+    const uint64_t *tab_first;
+    uint32_t *tab;
+    __device__ void operator()(uint64_t a) const
+    {
+        const uint64_t ak = a_keys[a];
+        const uint32_t i = key_row(ak), k = key_col(ak);
+        const uint64_t cand = rc(i);
+        const uint32_t n = win_count(cand, ncols, cw);
+        if (!n) return;
+        const uint32_t w = win_width(cand, ncols, cw);
+        uint32_t bb = 0, be = 0, off = ~0u;
+        if (k < b_block_rows) {
+            bb = b_rowptr[k]; be = b_rowptr[k + 1];
+            if (b_idx_row) off = b_idx_row[k];
+        }
+        uint32_t *out = tab + tab_first[i] + (uint64_t)(a - rc.a_rowptr[i]) * (n + 1u);
+        uint32_t pos = bb;  // edges ascend: a short block-row is walked once
+        for (uint32_t q = 0; q <= n; q++) {
+            const uint32_t edge = q * w;
+            uint32_t p;
+            if (q == 0) p = bb;
+            else if (edge >= ncols) p = be;
+            else if (off != ~0u) p = b_idx[off + edge / kWinGran];
+            else {
+                while (pos < be && key_col(b_keys[pos]) < edge) pos++;
+                p = pos;
+            }
+            out[q] = p;
         }
     }
 };
 
 struct WinArgs {
     const uint64_t *a_keys, *a_bmps;
-    const uint32_t *a_join;   // per A tile {B's block-row of its column: first tile, one past the last, place of that block-row's column index (~0: none), 0}
+    const uint32_t *stretch;  // the stretch table (BuildStretch)
     const uint32_t *a_rowptr;
     const uint64_t *b_keys, *b_bmps;
     const uint32_t *b_recs;   // per B tile {bitmap row-major (lo, hi), block column, rows the tile uses}: all a pass needs, one 16-byte load
@@ -108,7 +164,7 @@ struct WinArgs {
     const uint32_t *tile_base, *task_base;  // per window: first C tile, first task
     const uint64_t *val_base;               //             first value
     uint64_t *c_keys, *c_bmps, *c_offs;
-    uint32_t *task_begin;
+    uint32_t *task_begin, *c_of_wave;
     uint64_t *tasks;
     unsigned long long *prof;  // BMSP_WIN_PROF=1: per window {clocks of the count pass, of its look-ups, clocks of the fill pass, of its look-ups}
 };
@@ -118,99 +174,43 @@ struct WinArgs {
 #endif
 constexpr int kWinWaves = BMSP_WIN_WAVES;       // waves per workgroup
 constexpr int kWinThreads = 64 * kWinWaves;
-constexpr int kWinTiles = 64 / kWinWaves;       // A tiles of a round (64) a wave looks up; their lanes (64 / kWinTiles each) work together
-constexpr int kWinLanes = 64 / kWinTiles;
 constexpr int kWinBatch = 4;                    // steps whose records a wave requests together, fill pass (8-byte half records)
 constexpr int kWinBatchCount = 4;               // ... count pass (16-byte records)
 
-// A ROUND = 64 consecutive A tiles of the block-row.  Their stretches of B's block-rows inside the window are cut into STEPS of 64 tiles;
-// the round's steps are dealt to the workgroup's waves in turn (step i to wave i mod 8), so that one hub block-row of B among the 64
-// does not leave seven waves waiting at the round's barrier, and a wave requests the records of several steps -- of whatever A tiles --
-// together (the passes are bound by memory round trips: ~1.5 us each under load, measured).
-struct alignas(16) RoundTable {
-    uint32_t seg[64];   // first tile of B's block-row k inside the window
-    uint32_t len[64];   // tiles of it inside the window = candidate pairs of the A tile
-    uint64_t abm[64];
-};
-
-// first tile in [lo, hi) whose block column is >= col; the kWinLanes lanes of a group (same lo, hi, col; sub = lane inside the group,
-// shift = first lane of the group) probe kWinLanes interior points per round trip (operands whose column index was not built)
-__device__ __forceinline__ uint32_t lower_bound_col_group(const uint64_t *keys, uint32_t lo, uint32_t hi, uint32_t col, uint32_t sub, uint32_t shift)
-{
-    while (__any(lo < hi)) {
-        const uint32_t n = hi > lo ? hi - lo : 0u;
-        bool less = false;
-        if (n) less = key_col(keys[lo + (n * (sub + 1u)) / (uint32_t)(kWinLanes + 1)]) < col;
-        const uint32_t c = (uint32_t)__popcll((__ballot(less) >> shift) & ((1ull << kWinLanes) - 1ull));  // probes below col: the lower ones (keys ascend)
-        if (n) {
-            const uint32_t nlo = c ? lo + (n * c) / (uint32_t)(kWinLanes + 1) + 1u : lo;
-            const uint32_t nhi = c < (uint32_t)kWinLanes ? lo + (n * (c + 1u)) / (uint32_t)(kWinLanes + 1) : hi;
-            lo = nlo; hi = nhi;
-        }
-    }
-    return lo;
-}
-
+// A ROUND = 64 consecutive A tiles of the block-row.  Their stretches of B's block-rows inside the window (one stretch-table load per A
+// tile) are cut into STEPS of 64 tiles; the round's steps are dealt to the workgroup's waves in turn (step i to wave i mod 8), so that one
+// hub block-row of B among the 64 does not leave seven waves waiting at the round's barrier, and a wave requests the records of several
+// steps -- of whatever A tiles -- together (the passes are bound by memory round trips: ~0.75 us each, measured).  Every wave loads the
+// round's 64 table entries itself (lane v = A tile v of the round): no look-up phase to share, no barrier for it.
 typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
 
-// wave w's share of the round's look-ups: A tiles r0 + 8 w ... + 7 (those below a1): B's block-row cut to the window.  One load of the A
-// tile's join record {B's block-row: first tile, one past the last, place of its column index}, then: long block-rows answer from the
-// column index (two loads), short ones (<= kIdxMinLen tiles = two per lane of the group) are looked at whole.
-__device__ __forceinline__ void round_prologue(const WinArgs &g, const WinUnit &u, uint32_t ncols_all, RoundTable &R, uint32_t r0, uint32_t a1, int w, int lane)
-{
-    const uint32_t tile = (uint32_t)lane / (uint32_t)kWinLanes, sub = (uint32_t)lane % (uint32_t)kWinLanes, shift = tile * (uint32_t)kWinLanes;
-    const uint32_t v = (uint32_t)(kWinTiles * w) + tile, a = r0 + v;
-    uint32_t bb = 0, be = 0, off = ~0u;
-    uint64_t abm = 0;
-    if (a < a1) {
-        const u32x4w j = ((const u32x4w *)g.a_join)[a];
-        abm = g.a_bmps[a];
-        bb = j[0]; be = j[1]; off = j[2];
-    }
+struct RoundLoad {  // what a lane requests for its A tile of a round
     uint32_t s0, s1;
-    if (g.b_idx) {  // (kernel-uniform)
-        const bool cut_lo = u.lo != 0u, cut_hi = u.hi < ncols_all;
-        s0 = bb; s1 = be;
-        if (off != ~0u) {
-            if (cut_lo) s0 = g.b_idx[off + u.lo / kWinGran];
-            if (cut_hi) s1 = g.b_idx[off + u.hi / kWinGran];
-        }
-        // short block-rows: the lanes of the group look at all of its tiles together; tiles below an edge = where the edge cuts
-        const bool small = off == ~0u && be > bb;
-        constexpr int kProbes = ((int)kIdxMinLen + kWinLanes - 1) / kWinLanes;
-        uint32_t c[kProbes];
-#pragma unroll
-        for (int p = 0; p < kProbes; p++) {
-            c[p] = ~0u;
-            if (small && bb + (uint32_t)(p * kWinLanes) + sub < be) c[p] = key_col(g.b_keys[bb + (uint32_t)(p * kWinLanes) + sub]);
-        }
-        const uint64_t gm = (1ull << kWinLanes) - 1ull;
-        uint32_t below_lo = 0, below_hi = 0;
-#pragma unroll
-        for (int p = 0; p < kProbes; p++) {
-            below_lo += (uint32_t)__popcll((__ballot(c[p] < u.lo) >> shift) & gm);
-            below_hi += (uint32_t)__popcll((__ballot(c[p] < u.hi) >> shift) & gm);
-        }
-        if (small) { s0 = bb + below_lo; s1 = bb + below_hi; }
-    } else {
-        s0 = u.lo ? lower_bound_col_group(g.b_keys, bb, be, u.lo, sub, shift) : bb;
-        s1 = u.hi < ncols_all ? lower_bound_col_group(g.b_keys, s0, be, u.hi, sub, shift) : be;
+    uint64_t abm;
+};
+__device__ __forceinline__ RoundLoad round_load(const WinArgs &g, const WinUnit &u, uint32_t r0, int lane)
+{
+    RoundLoad r{0u, 0u, 0ull};
+    const uint32_t a = r0 + (uint32_t)lane;
+    if (a < u.a1) {
+        const uint32_t *e = g.stretch + u.tab + (size_t)(a - u.a0) * u.stride;
+        r.s0 = e[0]; r.s1 = e[1];
+        r.abm = g.a_bmps[a];
     }
-    if (sub == 0) { R.seg[v] = s0; R.len[v] = s1 - s0; R.abm[v] = abm; }
+    return r;
 }
 
-// what a wave keeps of the round after the barrier: lane v holds A tile v of the round; P = steps of the round in front of the tile
+// lane v holds A tile v of the round; P = steps of the round in front of the tile
 struct RoundRegs {
     uint32_t seg, len, alo, ahi, P;
     uint32_t S;  // steps of the round (uniform)
 };
-__device__ __forceinline__ RoundRegs round_regs(const RoundTable &R, int lane)
+__device__ __forceinline__ RoundRegs round_regs(const RoundLoad &r)
 {
     RoundRegs q;
-    q.seg = R.seg[lane]; q.len = R.len[lane];
-    const uint64_t a = R.abm[lane];
-    q.alo = (uint32_t)a; q.ahi = (uint32_t)(a >> 32);
+    q.seg = r.s0; q.len = r.s1 - r.s0;
+    q.alo = (uint32_t)r.abm; q.ahi = (uint32_t)(r.abm >> 32);
     const uint32_t steps = (q.len + 63u) >> 6;
     const uint32_t inc = wave_inclusive_sum(steps);
     q.P = inc - steps;
@@ -287,23 +287,20 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_count_kernel(WinArgs g, ui
 {
     __shared__ uint32_t cnt[T];
     __shared__ uint64_t bmp[T];
-    __shared__ RoundTable rt[2];
     __shared__ uint32_t red[kWinWaves], red2[2 * kWinWaves];
     constexpr int PT = T / kWinThreads;
     const uint32_t unit = blockIdx.x;
     const WinUnit u = g.units[unit];
     const int w = wave_id(), lane = lane_id();
     for (int s = threadIdx.x; s < T; s += kWinThreads) { cnt[s] = 0u; bmp[s] = 0ull; }
-    const uint32_t a0 = g.a_rowptr[u.row], a1 = g.a_rowptr[u.row + 1];
     const u32x4w *recs = (const u32x4w *)g.b_recs;
     const unsigned long long clk0 = g.prof ? __builtin_amdgcn_s_memtime() : 0ull;
-    unsigned long long clk_look = 0;
-    for (uint32_t r0 = a0, par = 0; r0 < a1; r0 += 64u, par ^= 1u) {
-        const unsigned long long c0 = g.prof ? __builtin_amdgcn_s_memtime() : 0ull;
-        round_prologue(g, u, ncols_all, rt[par], r0, a1, w, lane);
-        __syncthreads();  // (also orders the table's zeroing before the first update; the other round table is free again: every wave has its copy)
-        if (g.prof) clk_look += __builtin_amdgcn_s_memtime() - c0;
-        const RoundRegs q = round_regs(rt[par], lane);
+    RoundLoad nxt = round_load(g, u, u.a0, lane);
+    __syncthreads();  // the tables are zero
+    // (no barrier inside: the waves walk the rounds on their own, each with the next round's table entries already requested)
+    for (uint32_t r0 = u.a0; r0 < u.a1; r0 += 64u) {
+        const RoundRegs q = round_regs(nxt);
+        if (r0 + 64u < u.a1) nxt = round_load(g, u, r0 + 64u, lane);
         for (uint32_t i0 = (uint32_t)w; i0 < q.S; i0 += (uint32_t)(kWinWaves * kWinBatchCount)) {
             StepScalars t[kWinBatchCount];
             u32x4w r[kWinBatchCount];
@@ -355,7 +352,7 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_count_kernel(WinArgs g, ui
         g.u_tiles[unit] = tiles;
         g.u_surv[unit] = s1;
         g.u_nnz[unit] = s2;
-        if (g.prof) { g.prof[4 * unit] = __builtin_amdgcn_s_memtime() - clk0; g.prof[4 * unit + 1] = clk_look; }
+        if (g.prof) { g.prof[4 * unit] = __builtin_amdgcn_s_memtime() - clk0; g.prof[4 * unit + 1] = 0; }
     }
 }
 
@@ -365,7 +362,6 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g, uin
 {
     __shared__ uint32_t begin[T];    // first free task slot of the column's C tile, relative to the window's first task
     __shared__ uint64_t hit2[2][T];  // A tiles of the round (bit = A tile - the round's first) that meet the column; rounds alternate between the two
-    __shared__ RoundTable rt[2];
     __shared__ uint32_t red[kWinWaves];
     constexpr int PT = T / kWinThreads;
     const uint32_t unit = blockIdx.x;
@@ -400,22 +396,21 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g, uin
                 g.c_bmps[tb + r] = bm[i];
                 g.c_offs[tb + r] = vb + (uint64_t)en;   // T_9's popcount scan (:1113-1130)
                 g.task_begin[tb + r] = kb + ec;          // T_6's task ranges (:1040-1062)
+                // C tile of task 64 m, for every such task in this tile's range (what the task-list block-MAC kernels index per 64 tasks)
+                for (uint32_t m = (kb + ec + 63u) >> 6; (m << 6) < kb + ec + c[i]; m++) g.c_of_wave[m] = tb + r;
                 begin[col[i] - u.lo] = ec;
             }
             ec += c[i];
             en += (uint32_t)__popcll(bm[i]);
         }
     }
-    const uint32_t a0 = g.a_rowptr[u.row], a1 = g.a_rowptr[u.row + 1];
     const u32x2w *recs = (const u32x2w *)g.b_recs;  // {block column, rows the tile uses} = the upper half of a record
     const unsigned long long clk0 = g.prof ? __builtin_amdgcn_s_memtime() : 0ull;
-    unsigned long long clk_look = 0;
-    for (uint32_t r0 = a0, par = 0; r0 < a1; r0 += 64u, par ^= 1u) {
-        const unsigned long long c0 = g.prof ? __builtin_amdgcn_s_memtime() : 0ull;
-        round_prologue(g, u, ncols_all, rt[par], r0, a1, w, lane);
-        __syncthreads();  // the round's look-ups are in; the previous round's second half is over (and C's arrays / `begin` are written)
-        if (g.prof) clk_look += __builtin_amdgcn_s_memtime() - c0;
-        const RoundRegs q = round_regs(rt[par], lane);
+    RoundLoad nxt = round_load(g, u, u.a0, lane);
+    for (uint32_t r0 = u.a0, par = 0; r0 < u.a1; r0 += 64u, par ^= 1u) {
+        const RoundRegs q = round_regs(nxt);
+        if (r0 + 64u < u.a1) nxt = round_load(g, u, r0 + 64u, lane);
+        __syncthreads();  // the previous round's second half is over (first round: C's arrays and `begin` are written, the masks are zero)
         uint64_t *const hit = hit2[par];
         // the previous round's marks become task slots taken, while this round's first records travel
         StepScalars t0[kWinBatch];
@@ -426,7 +421,7 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g, uin
             f[b] = u32x2w{0u, 0u};
             if (t0[b].ok && t0[b].x0 + (uint32_t)lane < t0[b].len) f[b] = recs[2u * (t0[b].s0 + t0[b].x0 + (uint32_t)lane) + 1u];
         }
-        if (r0 != a0) {
+        if (r0 != u.a0) {
             uint64_t *const prev = hit2[par ^ 1u];
             for (int s = threadIdx.x; s < T; s += kWinThreads) {
                 const uint64_t h = prev[s];
@@ -474,24 +469,23 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g, uin
             for (int b = 0; b < kWinBatch; b++) place(t[b], r[b]);
         }
     }
-    if (g.prof && threadIdx.x == 0) { g.prof[4 * unit + 2] = __builtin_amdgcn_s_memtime() - clk0; g.prof[4 * unit + 3] = clk_look; }
+    if (g.prof && threadIdx.x == 0) { g.prof[4 * unit + 2] = __builtin_amdgcn_s_memtime() - clk0; g.prof[4 * unit + 3] = 0; }
 }
 
-struct JoinA {
-    const uint64_t *a_keys;
-    const uint32_t *b_rowptr, *b_idx_row;
-    uint32_t b_block_rows;
-    uint32_t *out;
-    __device__ void operator()(uint64_t a) const
+struct TilesSurvIn {
+    const uint32_t *tiles, *surv;
+    uint64_t n;
+    __device__ uint64_t operator()(uint64_t i) const { return i < n ? ((uint64_t)tiles[i] << 32) | (uint64_t)surv[i] : 0ull; }
+};
+struct TilesSurvOut {
+    uint32_t *tile_base, *task_base;
+    uint64_t n;
+    uint32_t *h_tiles, *h_tasks;
+    __device__ void operator()(uint64_t i, uint64_t ex) const
     {
-        const uint32_t k = key_col(a_keys[a]);
-        uint32_t bb = 0, be = 0, off = ~0u;
-        if (k < b_block_rows) {
-            bb = b_rowptr[k]; be = b_rowptr[k + 1];
-            if (b_idx_row) off = b_idx_row[k];
-        }
-        uint32_t *r = out + 4 * a;
-        r[0] = bb; r[1] = be; r[2] = off; r[3] = 0u;
+        tile_base[i] = (uint32_t)(ex >> 32);
+        task_base[i] = (uint32_t)ex;
+        if (i == n) { *h_tiles = (uint32_t)(ex >> 32); *h_tasks = (uint32_t)ex; }
     }
 };
 struct CntU32In {
@@ -508,22 +502,6 @@ struct RowPtrOfUnits {
     const uint32_t *unit_first, *tile_base;
     uint32_t *c_rowptr;
     __device__ void operator()(uint64_t i) const { c_rowptr[i] = tile_base[unit_first[i]]; }
-};
-struct COfWaveW {
-    const uint32_t *task_begin;
-    uint32_t c_size;
-    uint32_t *out;
-    __device__ void operator()(uint64_t w) const
-    {
-        const uint32_t t = (uint32_t)(w * 64);
-        uint32_t lo = 0, hi = c_size - 1u;  // last c with task_begin[c] <= t
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1u) >> 1;
-            if (task_begin[mid] <= t) lo = mid;
-            else hi = mid - 1u;
-        }
-        out[w] = lo;
-    }
 };
 struct SetOne64 {
     uint64_t *p;
@@ -565,17 +543,21 @@ bool rowmerge_windowed(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     HostScalar<uint64_t> n_scr_h;
     device_exclusive_scan<uint32_t>(PlanUnitsIn{rc, rows, ncols, cw}, PtrOutTotal<uint32_t>{unit_first.p, rows, n_units_h.dev()}, rows + 1, st);
     device_exclusive_scan<uint64_t>(PlanScratchIn{rc, rows, ncols}, PtrOutTotal<uint64_t>{scr_first.p, rows, n_scr_h.dev()}, rows + 1, st);
+    DevBuf<uint64_t> tab_first(rows + 1);
+    HostScalar<uint64_t> n_tab_h;
+    device_exclusive_scan<uint64_t>(PlanTableIn{rc, rows, ncols, cw}, PtrOutTotal<uint64_t>{tab_first.p, rows, n_tab_h.dev()}, rows + 1, st);
     const uint32_t U = n_units_h.wait(st);
-    const uint64_t S = n_scr_h.wait(st);
-    if (U == 0 || U >= (1u << 31) || S >= (1ull << 32) || S * 16 > (24ull << 30)) return false;
+    const uint64_t S = n_scr_h.wait(st), NT = n_tab_h.wait(st);
+    if (U == 0 || U >= (1u << 31) || S >= (1ull << 32) || S * 16 > (24ull << 30) || NT >= (1ull << 32)) return false;
     DevBuf<WinUnit> units(U);
-    device_for_each(EmitUnits{rc, ncols, cw, unit_first.p, scr_first.p, units.p}, rows, st);
+    device_for_each(EmitUnits{rc, ncols, cw, unit_first.p, scr_first.p, tab_first.p, units.p}, rows, st);
+    DevBuf<uint32_t> stretch(NT);
+    device_for_each(BuildStretch{rc, ncols, cw, A->keys, B->keys, B->rowptr, B->col_index_row, B->col_index, (uint32_t)B->num_block_rows(), tab_first.p, stretch.p},
+                    (uint64_t)A->block_num, st);
     DevBuf<uint32_t> t_col(S), t_cnt(S), u_tiles((size_t)U + 1), u_surv((size_t)U + 1), u_nnz((size_t)U + 1);
     DevBuf<uint64_t> t_bmp(S);
-    DevBuf<uint32_t> a_join(4 * (size_t)A->block_num);
-    device_for_each(JoinA{A->keys, B->rowptr, B->col_index_row, (uint32_t)B->num_block_rows(), a_join.p}, (uint64_t)A->block_num, st);
     WinArgs g{};
-    g.a_join = a_join.p;
+    g.stretch = stretch.p;
     g.a_keys = A->keys; g.a_bmps = A->bmps; g.a_rowptr = A->rowptr;
     g.b_keys = B->keys; g.b_bmps = B->bmps; g.b_recs = B->sym_recs; g.b_rowptr = B->rowptr; g.b_idx_row = B->col_index_row; g.b_idx = B->col_index; g.b_block_rows = (uint32_t)B->num_block_rows();
     g.units = units.p; g.n_units = U;
@@ -592,8 +574,8 @@ bool rowmerge_windowed(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     DevBuf<uint64_t> val_base((size_t)U + 1);
     HostScalar<uint32_t> c_size_h, n_tasks_h;
     HostScalar<uint64_t> nnz_h;
-    device_exclusive_scan<uint32_t>(CntU32In{u_tiles.p, U}, PtrOutTotal<uint32_t>{tile_base.p, U, c_size_h.dev()}, (uint64_t)U + 1, st);
-    device_exclusive_scan<uint32_t>(CntU32In{u_surv.p, U}, PtrOutTotal<uint32_t>{task_base.p, U, n_tasks_h.dev()}, (uint64_t)U + 1, st);
+    // (C tiles <= surviving pairs <= candidate pairs < 2^32: both running sums fit the halves of one 64-bit scan)
+    device_exclusive_scan<uint64_t>(TilesSurvIn{u_tiles.p, u_surv.p, U}, TilesSurvOut{tile_base.p, task_base.p, U, c_size_h.dev(), n_tasks_h.dev()}, (uint64_t)U + 1, st);
     device_exclusive_scan<uint64_t>(CntU64In{u_nnz.p, U}, PtrOutTotal<uint64_t>{val_base.p, U, nnz_h.dev()}, (uint64_t)U + 1, st);
     const uint32_t c_size = c_size_h.wait(st), n_tasks = n_tasks_h.wait(st);
     const uint64_t c_nnz = nnz_h.wait(st);
@@ -614,10 +596,9 @@ bool rowmerge_windowed(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     device_for_each(SetOne32{task_begin.p + c_size, n_tasks}, 1, st);
     if (c_size) {
         g.tile_base = tile_base.p; g.task_base = task_base.p; g.val_base = val_base.p;
-        g.c_keys = C->keys; g.c_bmps = C->bmps; g.c_offs = C->offsets; g.task_begin = task_begin.p; g.tasks = tasks.p;
+        g.c_keys = C->keys; g.c_bmps = C->bmps; g.c_offs = C->offsets; g.task_begin = task_begin.p; g.c_of_wave = c_of_wave.p; g.tasks = tasks.p;
         hipLaunchKernelGGL(rowwin_fill_kernel<kWinSlots>, dim3(U), dim3(kWinThreads), 0, st, g, ncols);
         BMSP_CHECK_LAUNCH();
-        device_for_each(COfWaveW{task_begin.p, c_size, c_of_wave.p}, ((uint64_t)n_tasks + 63) / 64, st);
     }
     if (g.prof) {  // experiment: the slowest windows, with what they hold
         std::vector<unsigned long long> hp(4 * (size_t)U);
