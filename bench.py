@@ -48,6 +48,7 @@ def parse(argv=None):
     ap.add_argument("--skip-spgemm", action="store_true")
     ap.add_argument("--skip-structures", action="store_true", help="skip the banded SpMV structures")
     ap.add_argument("--skip-vendor", action="store_true", help="skip the rocSPARSE comparison column")
+    ap.add_argument("--skip-rmat22", action="store_true", help="skip the scale-22 R-MAT product (configs[4] on one GPU: ~40 s of generation + build)")
     ap.add_argument("--only-spgemm", default="", help="experiment: run only the SpGEMM case whose tag contains this (fem | cage | ceiling)")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="bound on the CPU-baseline work, all legs together")
     ap.add_argument("--vendor-timeout", type=float, default=150.0, help="the rocSPARSE column runs in a child process; on a fresh box paging librocsparse in can take minutes")
@@ -101,6 +102,17 @@ def launch_ranks(args, argv, cmd=None):
         print("[bench] --gpus %d: %s" % (args.gpus, err or "child exit code %d" % r.returncode), file=sys.stderr, flush=True)
         return r.returncode or 3
     return 0
+
+
+# SuiteSparse dimensions of the BASELINE configs (top): rows = cols, entries after symmetric expansion.  Asserted
+# whenever --mtx-dir supplies the file, so that a stand-in or a truncated download can never pass for the named matrix.
+SUITESPARSE_DIMS = {"cant.mtx": (62451, 4007383), "webbase-1M.mtx": (1000005, 3105536), "2cubes_sphere.mtx": (101492, 1647264), "cage12.mtx": (130228, 2032536)}
+
+
+def assert_suitesparse_dims(fname, info):
+    rows, nnz = SUITESPARSE_DIMS[os.path.basename(fname)]
+    got = (info["num_rows"], info["num_cols"], info["nnz"])
+    assert got == (rows, rows, nnz), "%s: expected %d x %d with %d entries (SURVEY.md section 8), the file holds %d x %d with %d" % ((fname, rows, rows, nnz) + got)
 
 
 def csr_bytes(rows, nnz):
@@ -308,6 +320,7 @@ def main():
     note("SpMV workload generated")
     if "path" in wl:
         first = B.BmSpMatrix.from_mtx(wl["path"])
+        assert_suitesparse_dims(wl["path"], first.info())
     else:
         n, _, r, c, v = wl["coo"]
         first = B.BmSpMatrix.from_coo(n, n, r, c, v)
@@ -393,6 +406,9 @@ def main():
             out["spgemm_sharded_gflops"] = sg.get("gflops")
             out["spgemm_single_gpu_gflops"] = sg.get("single_gpu_gflops")
             out["spgemm_sharded_speedup"] = sg.get("speedup_vs_single_gpu")
+            out["spgemm_owner_keeps_gflops"] = sg.get("owner_keeps", {}).get("gflops")
+            out["spgemm_owner_keeps_speedup"] = sg.get("owner_keeps", {}).get("speedup_vs_single_gpu")
+            out["spgemm_exchange_hidden_frac"] = sg.get("exchange_hidden_frac")
         except Exception as e:  # noqa: BLE001
             out["spgemm_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if use_dist:
@@ -448,6 +464,10 @@ SPGEMM_CASES = [
     ("fem", "2cubes_sphere-like fem_like(47^3 grid, poisson27pt, windowed random renumbering)", lambda g: g.fem_like(47, "27pt"), "F32", 5, "2cubes_sphere.mtx", "spgemm_fem_like"),
     ("cage", "cage12-like local+random(130228, 15.6/row)", lambda g: g.cage_like(130228, 15.6), "F16", 4, "cage12.mtx", "spgemm_cage_like"),
     ("ceiling", "dense-tile ceiling: banded(147456, half_bw=256), 65 full 8x8 tiles per block-row, 7.8e7 tasks, 32.8 per C tile", lambda g: g.banded(147456, 256), "F16", 4, None, "spgemm_ceiling"),
+    # power-law operands (hub block-rows: C is a fifth full at tile granularity): the column-window passes (rowwindow.hip)
+    ("rmat16", "rmat(scale=16, edge_factor=8)+I: 1.46e8 candidate pairs, 6.4e7 tasks, 4.5 per C tile", lambda g: g.rmat(16, 8), "F16", 4, None, "spgemm_rmat16"),
+    # configs[4]'s product on ONE GPU (the N = 1 value of the sharded figure): 2.3e9 candidate pairs, run in block-row panels
+    ("rmat22", "rmat(scale=22, edge_factor=1)+I (configs[4] on one GPU): 2.29e9 candidate pairs, 6.9e8 tasks, 4.8e8 C tiles, 1.44 per C tile", lambda g: g.rmat(22, 1), "F16", 4, None, "spgemm_rmat22"),
 ]
 MAC_VARIANT = {0: "default kernel of the tc_version", 1: "block_mac_mfma32_kernel (K = 32, LDS-staged)", 2: "block_mac_direct_kernel (K = 32, lines per task)",
                3: "block_mac_strip_kernel (K = 32, two block-rows per wave, operand reuse)", 4: "block_mac_f32_mfma_kernel (v_mfma_f32_16x16x4_f32, V15 chain, lane-ordered tile copies)"}
@@ -502,11 +522,14 @@ def bench_spgemm(B, gen, np, args):
     for tag, name, mk, dtn, tc, fname, ptag in SPGEMM_CASES:
         if args.only_spgemm and args.only_spgemm not in tag:
             continue
+        if tag == "rmat22" and args.skip_rmat22 and not args.only_spgemm:
+            continue
         dtype = getattr(B, dtn)
         path = os.path.join(args.mtx_dir, fname) if (args.mtx_dir and fname) else ""
         if path and os.path.exists(path):
             A = B.BmSpMatrix.from_mtx(path, False, dtype)
             At = B.BmSpMatrix.from_mtx(path, True, dtype)
+            assert_suitesparse_dims(path, A.info())
             name = fname + " (SuiteSparse file)"
         else:
             n, _, r, c, v = mk(gen)
@@ -528,7 +551,7 @@ def bench_spgemm(B, gen, np, args):
         first_call_ms = (time.perf_counter() - t0) * 1e3
         del Cm
         runs = []
-        n_runs = 5 if tag == "ceiling" else 8
+        n_runs = 5 if tag == "ceiling" else (3 if tag == "rmat22" else 8)
         for it in range(n_runs):  # one more call warms the pool; median of the rest
             t0 = time.perf_counter()
             Cm, st = B.spgemm(A, At, mode=B.SORT_AUTO, tc_version=tc)
@@ -541,6 +564,8 @@ def bench_spgemm(B, gen, np, args):
         # the numeric half alone on a C that already has the structure (bmsp_spgemm_numeric: new values on an old pattern)
         numeric_ms = None
         try:
+            if tag == "rmat22":
+                raise RuntimeError("not measured on this case (a paneled product keeps no task list)")
             Cs, _ = B.spgemm_symbolic(A, At, mode=B.SORT_AUTO, tc_version=tc)
             nm = []
             for it in range(4):
@@ -648,7 +673,7 @@ def vendor_column(np, gen, wl, eff_bytes, args):
     if not args.skip_spgemm:
         res["spgemm"] = []
         for tag, name, mk, dtn, tc, fname, ptag in SPGEMM_CASES:
-            if tag == "ceiling" or (args.only_spgemm and args.only_spgemm not in tag):
+            if tag in ("ceiling", "rmat16", "rmat22") or (args.only_spgemm and args.only_spgemm not in tag):
                 continue
             m, ptr, col, val = csr_of(mk(gen))
             note("vendor: CSR of %s built" % tag)
@@ -699,18 +724,27 @@ def bench_spgemm_sharded(B, gen, np, torch, dist, rank, world):
     A = B.BmSpMatrix.from_coo(n, n, r, c, v, dtype=B.F16).prepare(2)
     Bt = B.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=B.F16).prepare(2)
     comm = B.Comm.from_torch(dist, torch)
-    best = None
-    for it in range(3):
-        B.synchronize(); dist.barrier()
-        t0 = time.perf_counter()
-        Cm, st, sh = B.spgemm_sharded(comm, A, Bt, tc_version=4)
-        B.synchronize(); dist.barrier()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt, st["t_us"][0] * 1e-6], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        if it and (best is None or float(t[0].item()) < best[0]):
-            best = (float(t[0].item()), sh, Cm.info(), float(t[1].item()))
-        del Cm
+
+    def timed(gather):
+        best = None
+        for it in range(3):
+            B.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            Cm, st, sh = B.spgemm_sharded(comm, A, Bt, tc_version=4, gather=gather)
+            B.synchronize(); dist.barrier()
+            dt = time.perf_counter() - t0
+            t = torch.tensor([dt, st["t_us"][0] * 1e-6], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            blocks = torch.tensor([Cm.info()["block_num"], Cm.info()["nnz"]], dtype=torch.int64, device="cuda")
+            if not gather:
+                dist.all_reduce(blocks)  # owner keeps: every rank holds its panel; the product's size is the sum
+            if it and (best is None or float(t[0].item()) < best[0]):
+                best = (float(t[0].item()), sh, {"block_num": int(blocks[0].item()), "nnz": int(blocks[1].item())}, float(t[1].item()))
+            del Cm
+        return best
+
+    best = timed(True)       # every rank ends with the whole C: rounds of panels, a round's broadcasts behind the next round's products
+    keeps = timed(False)     # owner keeps: no exchange ("skip the gather and report it separately")
     comm.free()
     # the same product on ONE GPU (rank 0 alone, the other ranks wait at the barrier): the N = 1 value of this strong-scaling figure
     single = None
@@ -724,12 +758,19 @@ def bench_spgemm_sharded(B, gen, np, torch, dist, rank, world):
             del Cm
     dist.barrier()
     P = scalar_products(np, A) if rank == 0 else 0
+    sh = best[1]
     return {"workload": "row-panel-sharded SpGEMM fp16 MFMA, rmat(scale=%d, ef=%g)+I" % (scale, ef), "scaling": "strong", "n_gpus": world,
             "single_gpu_ms": round(single * 1e3, 3) if single else None, "single_gpu_gflops": round(2.0 * P / single / 1e9, 2) if single else None,
             "speedup_vs_single_gpu": round(single / best[0], 3) if single else None,
-            "total_ms": round(best[0] * 1e3, 3), "slowest_panel_product_ms": round(best[3] * 1e3, 3), "gflops": round(2.0 * P / best[0] / 1e9, 2),
-            "c_blocks": best[2]["block_num"], "c_nnz": best[2]["nnz"], "allgatherv_bytes": best[1]["exchange_bytes"],
-            "allgatherv_ms": round(best[1]["exchange_us"] * 1e-3, 3), "panel_tasks": best[1]["panel_tasks"]}
+            "total_ms": round(best[0] * 1e3, 3), "slowest_rank_products_ms": round(best[3] * 1e3, 3), "gflops": round(2.0 * P / best[0] / 1e9, 2),
+            "c_blocks": best[2]["block_num"], "c_nnz": best[2]["nnz"], "allgatherv_bytes": sh["exchange_bytes"], "rounds": sh["rounds"],
+            "allgatherv_ms": round(sh["exchange_us"] * 1e-3, 3), "allgatherv_exposed_ms": round(sh["exchange_exposed_us"] * 1e-3, 3),
+            "exchange_hidden_frac": round(sh["exchange_hidden_frac"], 3),
+            "allgatherv_GBs_per_rank": round(sh["exchange_bytes"] * (world - 1) / max(world, 1) / max(sh["exchange_us"], 1e-3) / 1e3, 1),
+            "panel_tasks": sh["panel_tasks"],
+            "owner_keeps": {"total_ms": round(keeps[0] * 1e3, 3), "gflops": round(2.0 * P / keeps[0] / 1e9, 2), "c_blocks": keeps[2]["block_num"], "c_nnz": keeps[2]["nnz"],
+                            "speedup_vs_single_gpu": round(single / keeps[0], 3) if single else None,
+                            "note": "every rank keeps its panel of C (bmsp_spgemm_sharded_ex, gather = 0): no exchange"}}
 
 
 def host_threads(O):
@@ -810,7 +851,7 @@ def cpu_baseline(wl, eff_bytes, args):
     if not args.skip_spgemm:
         out["spgemm"] = []
         for tag, name, mk, dtn, tc, fname, ptag in SPGEMM_CASES:
-            if tag == "ceiling" or (args.only_spgemm and args.only_spgemm not in tag):
+            if tag in ("ceiling", "rmat16", "rmat22") or (args.only_spgemm and args.only_spgemm not in tag):
                 continue
             gn, _, gr, gc, gv = mk(gen)
             G = O.csr_from_coo(O.Coo(gn, gn, gr, gc, gv))

@@ -549,7 +549,10 @@ int launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *t
     const char *de = getenv("BMSP_MAC_DIRECT");
     const bool direct = b_dense && (de ? de[0] == '1' : 10 * n_tasks >= 46 * (uint64_t)cs);
     const char *qenv = getenv("BMSP_MAC_QUOTA");
-    uint64_t quota = qenv ? (uint64_t)atoll(qenv) : (n_tasks + 32767) / 32768;
+    // (measured, T_7 in us at 256 / 512 / 1024 / 2048 / 4096 tasks per wave: R-MAT 2^16 x 8 2586 / 2496 / 2511 / 2548 / 2699, cage-like 427 (128) /
+    // 421 (512) / 454 (2048): short quotas keep an XCD's resident waves on few block-rows of B at a time -- capped at 512 while that leaves
+    // at most 2^20 waves)
+    uint64_t quota = qenv ? (uint64_t)atoll(qenv) : std::min<uint64_t>((n_tasks + 32767) / 32768, std::max<uint64_t>(512, n_tasks >> 20));
     quota = std::max<uint64_t>(256, (quota + 63) / 64 * 64);
     // the direct kernel reads every operand line from the L2 or beyond: short quotas keep the resident waves of an XCD on few block-rows
     // at a time, whose B tiles then meet in its L2 (FEM-like T_7: 584 us at 1024 tasks per wave, 574 at 768, 530 at 256, 526 at 128;

@@ -551,6 +551,15 @@ int bmsp_spgemm_sharded(bmsp_comm_t c, bmsp_matrix_t A, bmsp_matrix_t B, bmsp_ma
     BMSP_API_END
 }
 
+int bmsp_spgemm_sharded_ex(bmsp_comm_t c, bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, int verbose, void *stream,
+                           bmsp_spgemm_stats *stats, bmsp_shard_stats *shard, int gather, int rounds)
+{
+    BMSP_API_BEGIN
+    need(c, "comm"); need(A, "A"); need(B, "B"); need(C, "C");
+    spgemm_sharded(c, A, B, C, mode, tc_version, verbose, as_stream(stream), stats, shard, gather ? 1 : 0, rounds);
+    BMSP_API_END
+}
+
 int bmsp_spmv_sharded(bmsp_comm_t c, bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *stream, bmsp_shard_stats *shard)
 {
     BMSP_API_BEGIN

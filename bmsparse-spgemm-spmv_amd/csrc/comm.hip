@@ -36,6 +36,8 @@
 namespace bmsp {
 void partition_rows(bmsp_matrix_s *A, bmsp_matrix_s *B, int parts, int64_t *bounds, hipStream_t st, uint64_t *total_out);
 bmsp_matrix_s *row_panel(bmsp_matrix_s *m, int64_t rb, int64_t re, hipStream_t st);
+bmsp_matrix_s *concat_panels(int num_rows, int num_cols, int parts, const int64_t *block_nums, const int64_t *nnzs, uint64_t *const *d_keys, uint64_t *const *d_bmps,
+                             uint64_t *const *d_offsets, void *const *d_values, bmsp_dtype dtype, hipStream_t st);
 void spgemm_paneled(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int tc_version, int verbose, hipStream_t st,
                     bmsp_spgemm_stats *stats);
 
@@ -269,84 +271,204 @@ bmsp_comm_s *comm_init_from_env()
 void comm_free(bmsp_comm_s *c)
 {
     if (!c) return;
+    if (c->xstream) (void)hipStreamDestroy((hipStream_t)c->xstream);
     if (c->comm) (void)rccl().CommDestroy((ncclComm_t)c->comm);
     delete c;
 }
 
+namespace {
+struct CopyU64 {
+    const uint64_t *src;
+    uint64_t *dst;
+    __device__ void operator()(uint64_t i) const { dst[i] = src[i]; }
+};
+// one panel product (a sub-panel when the panel exceeds one task list), with the pair's row-merge hint carried over the views
+bmsp_matrix_s *panel_product(bmsp_matrix_s *A, bmsp_matrix_s *B, int64_t rb, int64_t re, int mode, int tc_version, int verbose, hipStream_t st, bmsp_spgemm_stats *one)
+{
+    std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> view(row_panel(A, rb, re, st), free_matrix);
+    rm_hint_inherit(view.get(), A);
+    bmsp_matrix_s *cp_raw = nullptr;
+    try {
+        spgemm(view.get(), B, &cp_raw, mode, tc_version, verbose, st, one);
+    } catch (const TaskRangeExceeded &) {  // a panel beyond one task list: run it in sub-panels (same answer)
+        spgemm_paneled(view.get(), B, &cp_raw, mode, tc_version, verbose, st, one);
+    }
+    rm_hint_merge(A, view.get());
+    return cp_raw;
+}
+void add_stats(bmsp_spgemm_stats &ps, const bmsp_spgemm_stats &one)
+{
+    ps.task_list_size += one.task_list_size; ps.bmp_reduction += one.bmp_reduction; ps.surviving_tasks += one.surviving_tasks;
+    ps.c_blocks += one.c_blocks; ps.c_nnz += one.c_nnz;
+    for (int i = 0; i < 10; i++) ps.t_us[i] += one.t_us[i];
+    ps.sort_path = one.sort_path; ps.mac_kernel = one.mac_kernel; ps.mac_variant = one.mac_variant;
+}
+}  // namespace
+
+// The sharded product.  gather = 1: every rank returns the whole C.  The block-rows of A are cut into ROUNDS x P panels balanced by
+// candidate-task count; rank r multiplies panels r, P + r, 2 P + r, ...  (round k = panels k P ... k P + P - 1, a contiguous stretch of
+// C's rows that precedes every later round's).  After round k the P panel sizes are gathered (one tiny ncclAllGather), which fixes where
+// the round's panels land in the whole C -- rounds are laid out in order, so nothing later can move them -- and the round's four arrays
+// are broadcast straight into their final slices ON A SECOND STREAM while round k + 1 multiplies on the caller's: the exchange of all but
+// the last round hides behind compute (xGMI copies against kernels; loopback: the copy engine against kernels, measurable on one GPU).
+// The whole C is allocated after round 0 from its sizes (x rounds x 1.25) and grown by copy if a later round does not fit.
+// gather = 0 ("owner keeps", SURVEY 8(e): "If only the owner needs C, skip the gather"): P panels, no exchange, *Cout = this rank's panel
+// with global keys (loopback: all P panels concatenated -- this process owns every one).
 void spgemm_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, int tc_version, int verbose,
-                    hipStream_t st, bmsp_spgemm_stats *stats, bmsp_shard_stats *sh)
+                    hipStream_t st, bmsp_spgemm_stats *stats, bmsp_shard_stats *sh, int gather, int rounds)
 {
     if (!c || !A || !B || !Cout) fail(BMSP_ERR_INVALID, "null argument");
+    if (rounds < 0 || rounds > 64) fail(BMSP_ERR_INVALID, "rounds must be 0 (library's choice) .. 64");
     const int P = c->world;
-    std::vector<int64_t> bounds((size_t)P + 1);
-    partition_rows(A, B, P, bounds.data(), st, nullptr);
-    // the panel products this process owns (its rank's; all P, one after another, in loopback)
     typedef std::unique_ptr<bmsp_matrix_s, void (*)(bmsp_matrix_s *)> MatPtr;
-    std::vector<MatPtr> cp;
-    for (int r = 0; r < P; r++) cp.emplace_back(nullptr, free_matrix);
-    std::vector<std::array<int64_t, 2>> local((size_t)P, std::array<int64_t, 2>{0, 0});
-    bmsp_spgemm_stats ps{};  // this rank's panel (loopback: summed over the panels, like the paneled single-GPU product)
-    for (int r : local_ranks(c)) {
-        MatPtr view(row_panel(A, bounds[(size_t)r], bounds[(size_t)r + 1], st), free_matrix);
-        rm_hint_inherit(view.get(), A);
-        bmsp_matrix_s *cp_raw = nullptr;
-        bmsp_spgemm_stats one{};
-        try {
-            spgemm(view.get(), B, &cp_raw, mode, tc_version, verbose, st, &one);
-        } catch (const TaskRangeExceeded &) {  // a panel beyond one task list: run it in sub-panels (same answer)
-            spgemm_paneled(view.get(), B, &cp_raw, mode, tc_version, verbose, st, &one);
-        }
-        rm_hint_merge(A, view.get());
-        cp[(size_t)r].reset(cp_raw);
-        local[(size_t)r] = {cp_raw->block_num, cp_raw->nnz};
-        ps.task_list_size += one.task_list_size; ps.bmp_reduction += one.bmp_reduction; ps.surviving_tasks += one.surviving_tasks;
-        ps.c_blocks += one.c_blocks; ps.c_nnz += one.c_nnz;
-        for (int i = 0; i < 10; i++) ps.t_us[i] += one.t_us[i];
-        ps.sort_path = one.sort_path; ps.mac_kernel = one.mac_kernel; ps.mac_variant = one.mac_variant;
-    }
     const bmsp_dtype cdt = A->dtype == BMSP_F64 ? BMSP_F64 : BMSP_F32;
-    StageTimer tm(st, true);
-    tm.mark(-1);
-    // sizes of every panel -> where every panel lands
-    std::vector<int64_t> sizes;
-    exchange_sizes(c, local, sizes, st);
-    std::vector<int64_t> nb((size_t)P), nz((size_t)P), b0((size_t)P + 1, 0), z0((size_t)P + 1, 0);
-    for (int r = 0; r < P; r++) { nb[(size_t)r] = sizes[(size_t)2 * r]; nz[(size_t)r] = sizes[(size_t)2 * r + 1]; }
-    shard_layout(P, nb.data(), nz.data(), b0.data(), z0.data());
-    const int64_t NB = b0[(size_t)P], NZ = z0[(size_t)P];
-    // the whole C at its final size; every panel travels straight into its slice
+    const size_t es = dtype_size(cdt);
+    bmsp_spgemm_stats ps{};  // this rank's panels (loopback: summed over all panels, like the paneled single-GPU product)
+    if (sh) *sh = bmsp_shard_stats{};
+
+    if (!gather) {
+        std::vector<int64_t> bounds((size_t)P + 1);
+        partition_rows(A, B, P, bounds.data(), st, nullptr);
+        std::vector<bmsp_matrix_s *> mine;
+        auto cleanup = [&]() { for (bmsp_matrix_s *m : mine) free_matrix(m); mine.clear(); };
+        try {
+            for (int r : local_ranks(c)) {
+                bmsp_spgemm_stats one{};
+                mine.push_back(panel_product(A, B, bounds[(size_t)r], bounds[(size_t)r + 1], mode, tc_version, verbose, st, &one));
+                add_stats(ps, one);
+            }
+            if (mine.size() == 1) {
+                *Cout = mine[0];
+                mine.clear();
+            } else {
+                std::vector<int64_t> bn, nz;
+                std::vector<uint64_t *> k, b, o;
+                std::vector<void *> v;
+                for (bmsp_matrix_s *m : mine) { bn.push_back(m->block_num); nz.push_back(m->nnz); k.push_back(m->keys); b.push_back(m->bmps); o.push_back(m->offsets); v.push_back(m->values); }
+                *Cout = concat_panels(A->num_rows, B->num_cols, (int)mine.size(), bn.data(), nz.data(), k.data(), b.data(), o.data(), v.data(), cdt, st);
+            }
+        } catch (...) {
+            cleanup();
+            throw;
+        }
+        cleanup();
+        if (stats) *stats = ps;
+        if (sh) {
+            sh->world = P; sh->rank = c->rank;
+            sh->panel_block_row_begin = bounds[(size_t)c->rank]; sh->panel_block_row_end = bounds[(size_t)c->rank + 1];
+            sh->panel_tasks = ps.surviving_tasks; sh->rounds = 1; sh->gathered = 0;
+        }
+        return;
+    }
+
+    const char *re = getenv("BMSP_SHARD_ROUNDS");
+    const int K = rounds ? rounds : (re ? std::max(1, std::min(64, atoi(re))) : (P > 1 ? 4 : 1));
+    const int Q = K * P;
+    std::vector<int64_t> bounds((size_t)Q + 1);
+    partition_rows(A, B, Q, bounds.data(), st, nullptr);
+    if (!c->xstream) BMSP_HIP(hipStreamCreateWithFlags((hipStream_t *)&c->xstream, hipStreamNonBlocking));
+    const hipStream_t xs = (hipStream_t)c->xstream;
+    std::vector<MatPtr> cp;
+    for (int q = 0; q < Q; q++) cp.emplace_back(nullptr, free_matrix);
     MatPtr C(new bmsp_matrix_s(), free_matrix);
     C->num_rows = A->num_rows; C->num_cols = B->num_cols; C->dtype = cdt; C->transposed = 0;
-    C->block_num = NB; C->nnz = NZ;
-    const size_t es = dtype_size(C->dtype);
-    C->keys = (uint64_t *)pool_alloc(8 * (size_t)(NB ? NB : 1));
-    C->bmps = (uint64_t *)pool_alloc(8 * (size_t)(NB ? NB : 1));
-    C->offsets = (uint64_t *)pool_alloc(8 * ((size_t)NB + 1));
-    C->values = pool_alloc(es * (size_t)(NZ ? NZ : 1));
-    std::vector<const void *> sk((size_t)P, nullptr), sb((size_t)P, nullptr), so((size_t)P, nullptr), sv((size_t)P, nullptr);
-    for (int r = 0; r < P; r++)
-        if (cp[(size_t)r]) { sk[(size_t)r] = cp[(size_t)r]->keys; sb[(size_t)r] = cp[(size_t)r]->bmps; so[(size_t)r] = cp[(size_t)r]->offsets; sv[(size_t)r] = cp[(size_t)r]->values; }
-    exchange_slices(c, sk, C->keys, nb.data(), b0.data(), 8, st);
-    exchange_slices(c, sb, C->bmps, nb.data(), b0.data(), 8, st);
-    exchange_slices(c, so, C->offsets, nb.data(), b0.data(), 8, st);  // block_num entries per panel (the terminal one is rebuilt)
-    exchange_slices(c, sv, C->values, nz.data(), z0.data(), es, st);
-    // a panel's offsets count from its own first value: re-base by the values in front of it
-    for (int r = 0; r < P; r++)
-        if (nb[(size_t)r] && z0[(size_t)r]) device_for_each(AddU64{C->offsets + b0[(size_t)r], (uint64_t)z0[(size_t)r]}, (uint64_t)nb[(size_t)r], st);
-    const uint64_t term = (uint64_t)NZ;
-    BMSP_HIP(hipMemcpyAsync(C->offsets + NB, &term, 8, hipMemcpyHostToDevice, st));
-    tm.mark(0);
-    BMSP_HIP(hipStreamSynchronize(st));
-    double t_us[10] = {0};
-    tm.collect(t_us);
-    if (stats) *stats = ps;
-    if (sh) {
-        sh->world = P; sh->rank = c->rank;
-        sh->panel_block_row_begin = bounds[(size_t)c->rank]; sh->panel_block_row_end = bounds[(size_t)c->rank + 1];
-        sh->panel_tasks = ps.surviving_tasks;
-        sh->exchange_bytes = 24 * NB + (int64_t)es * NZ;
-        sh->exchange_us = t_us[0];
+    int64_t cap_b = 0, cap_z = 0, base_b = 0, base_z = 0;
+    std::vector<hipEvent_t> evs;
+    auto new_event = [&](hipStream_t s) { hipEvent_t e; BMSP_HIP(hipEventCreate(&e)); evs.push_back(e); BMSP_HIP(hipEventRecord(e, s)); return e; };
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ex_spans;
+    hipEvent_t ev_compute_done = nullptr;
+    try {
+        for (int k = 0; k < K; k++) {
+            std::vector<std::array<int64_t, 2>> local((size_t)P, std::array<int64_t, 2>{0, 0});
+            for (int r : local_ranks(c)) {
+                const int q = k * P + r;
+                bmsp_spgemm_stats one{};
+                cp[(size_t)q].reset(panel_product(A, B, bounds[(size_t)q], bounds[(size_t)q + 1], mode, tc_version, verbose, st, &one));
+                local[(size_t)r] = {cp[(size_t)q]->block_num, cp[(size_t)q]->nnz};
+                add_stats(ps, one);
+            }
+            if (k == K - 1) ev_compute_done = new_event(st);
+            // sizes of the round's panels -> where they land (rounds are laid out one after the other)
+            std::vector<int64_t> sizes;
+            exchange_sizes(c, local, sizes, xs);  // (every RCCL call of the product on the exchange stream: one order on every rank)
+            std::vector<int64_t> nb((size_t)P), nz((size_t)P), b0((size_t)P + 1, 0), z0((size_t)P + 1, 0);
+            for (int r = 0; r < P; r++) { nb[(size_t)r] = sizes[(size_t)2 * r]; nz[(size_t)r] = sizes[(size_t)2 * r + 1]; }
+            shard_layout(P, nb.data(), nz.data(), b0.data(), z0.data());
+            const int64_t need_b = base_b + b0[(size_t)P], need_z = base_z + z0[(size_t)P];
+            if (need_b > cap_b || need_z > cap_z || !C->keys) {
+                // first round: the whole C from this round's sizes; later: a round that does not fit (the earlier rounds' slices move)
+                const int left = K - k;
+                const int64_t nb_cap = std::max<int64_t>(need_b, base_b + (int64_t)((double)b0[(size_t)P] * left * 1.25) + 1024);
+                const int64_t nz_cap = std::max<int64_t>(need_z, base_z + (int64_t)((double)z0[(size_t)P] * left * 1.25) + 1024);
+                BMSP_HIP(hipStreamSynchronize(xs));  // the broadcasts in flight write the arrays that move
+                uint64_t *nk = (uint64_t *)pool_alloc(8 * (size_t)nb_cap), *nbm = (uint64_t *)pool_alloc(8 * (size_t)nb_cap), *no = (uint64_t *)pool_alloc(8 * ((size_t)nb_cap + 1));
+                void *nv = pool_alloc(es * (size_t)(nz_cap ? nz_cap : 1));
+                if (base_b) {
+                    BMSP_HIP(hipMemcpyAsync(nk, C->keys, 8 * (size_t)base_b, hipMemcpyDeviceToDevice, st));
+                    BMSP_HIP(hipMemcpyAsync(nbm, C->bmps, 8 * (size_t)base_b, hipMemcpyDeviceToDevice, st));
+                    BMSP_HIP(hipMemcpyAsync(no, C->offsets, 8 * (size_t)base_b, hipMemcpyDeviceToDevice, st));
+                }
+                if (base_z) BMSP_HIP(hipMemcpyAsync(nv, C->values, es * (size_t)base_z, hipMemcpyDeviceToDevice, st));
+                BMSP_HIP(hipStreamSynchronize(st));
+                pool_free(C->keys); pool_free(C->bmps); pool_free(C->offsets); pool_free(C->values);
+                C->keys = nk; C->bmps = nbm; C->offsets = no; C->values = nv;
+                cap_b = nb_cap; cap_z = nz_cap;
+            }
+            // the round's panels straight into their final slices, on the exchange stream (the panel products are complete: spgemm returns
+            // synchronised); the next round's products run meanwhile
+            hipEvent_t e0 = new_event(xs);
+            std::vector<const void *> sk((size_t)P, nullptr), sb((size_t)P, nullptr), so((size_t)P, nullptr), sv((size_t)P, nullptr);
+            std::vector<int64_t> bs((size_t)P), zs((size_t)P);
+            for (int r = 0; r < P; r++) {
+                const bmsp_matrix_s *m = cp[(size_t)(k * P + r)].get();
+                if (m) { sk[(size_t)r] = m->keys; sb[(size_t)r] = m->bmps; so[(size_t)r] = m->offsets; sv[(size_t)r] = m->values; }
+                bs[(size_t)r] = base_b + b0[(size_t)r]; zs[(size_t)r] = base_z + z0[(size_t)r];
+            }
+            exchange_slices(c, sk, C->keys, nb.data(), bs.data(), 8, xs);
+            exchange_slices(c, sb, C->bmps, nb.data(), bs.data(), 8, xs);
+            exchange_slices(c, so, C->offsets, nb.data(), bs.data(), 8, xs);  // block_num entries per panel (the terminal one is rebuilt)
+            exchange_slices(c, sv, C->values, nz.data(), zs.data(), es, xs);
+            // a panel's offsets count from its own first value: re-base by the values in front of it
+            for (int r = 0; r < P; r++)
+                if (nb[(size_t)r] && zs[(size_t)r]) device_for_each(AddU64{C->offsets + bs[(size_t)r], (uint64_t)zs[(size_t)r]}, (uint64_t)nb[(size_t)r], xs);
+            ex_spans.emplace_back(e0, new_event(xs));
+            base_b = need_b; base_z = need_z;
+        }
+        const uint64_t term = (uint64_t)base_z;
+        BMSP_HIP(hipStreamSynchronize(xs));
+        hipEvent_t ev_all_done = new_event(xs);
+        BMSP_HIP(hipMemcpyAsync(C->offsets + base_b, &term, 8, hipMemcpyHostToDevice, st));
+        BMSP_HIP(hipStreamSynchronize(st));
+        BMSP_HIP(hipEventSynchronize(ev_all_done));
+        C->block_num = base_b; C->nnz = base_z;
+        double ex_us = 0.0, exposed_us = 0.0;
+        for (auto &sp : ex_spans) {
+            float ms = 0.f;
+            BMSP_HIP(hipEventElapsedTime(&ms, sp.first, sp.second));
+            ex_us += (double)ms * 1e3;
+        }
+        if (!ex_spans.empty() && ev_compute_done) {
+            float ms = 0.f;
+            BMSP_HIP(hipEventElapsedTime(&ms, ev_compute_done, ex_spans.back().second));
+            exposed_us = std::max(0.0, (double)ms * 1e3);
+        }
+        if (stats) *stats = ps;
+        if (sh) {
+            sh->world = P; sh->rank = c->rank;
+            sh->panel_block_row_begin = bounds[(size_t)c->rank]; sh->panel_block_row_end = bounds[(size_t)c->rank + 1];
+            sh->panel_tasks = ps.surviving_tasks;
+            sh->exchange_bytes = 24 * base_b + (int64_t)es * base_z;
+            sh->exchange_us = ex_us;
+            sh->exchange_exposed_us = std::min(exposed_us, ex_us);
+            sh->exchange_hidden_frac = ex_us > 0.0 ? 1.0 - std::min(exposed_us, ex_us) / ex_us : 0.0;
+            sh->rounds = K; sh->gathered = 1;
+        }
+    } catch (...) {
+        (void)hipStreamSynchronize(xs);
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        throw;
     }
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     *Cout = C.release();
 }
 

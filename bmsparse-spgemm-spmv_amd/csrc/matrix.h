@@ -78,6 +78,7 @@ struct bmsp_matrix_s {
 struct bmsp_comm_s {
     void *comm = nullptr;
     int rank = 0, world = 1, device = 0;
+    void *xstream = nullptr;  // the exchange stream of the sharded SpGEMM (a round's broadcasts run on it while the next round multiplies)
     int loopback = 0;  // 1: no RCCL -- every panel is computed by this process on this device, "broadcast" = device copy (comm.hip)
 };
 
@@ -183,7 +184,7 @@ void shard_row_slices(int num_rows, int parts, const int64_t *bounds, int64_t *r
 void invalidate_matrix(bmsp_matrix_s *m, int structure_changed);
 void comm_free(bmsp_comm_s *c);
 void spgemm_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **C, int mode, int tc_version, int verbose, hipStream_t st,
-                    bmsp_spgemm_stats *stats, bmsp_shard_stats *sh);
+                    bmsp_spgemm_stats *stats, bmsp_shard_stats *sh, int gather = 1, int rounds = 0);
 void spmv_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, const void *x, void *y, int variant, hipStream_t st, bmsp_shard_stats *sh);
 
 }  // namespace bmsp

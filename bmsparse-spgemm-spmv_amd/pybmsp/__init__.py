@@ -29,7 +29,7 @@ SYMBOLS = [
     "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_prepare", "bmsp_matrix_invalidate", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
     "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmv_launch_info", "bmsp_spmm", "bmsp_spgemm", "bmsp_spgemm_symbolic", "bmsp_spgemm_numeric", "bmsp_selftest_mfma_layout", "bmsp_selftest_mfma_f32_chain", "bmsp_selftest_tile_product", "bmsp_segsort_u64",
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
-    "bmsp_comm_unique_id", "bmsp_comm_init", "bmsp_comm_init_from_env", "bmsp_comm_init_loopback", "bmsp_shard_layout", "bmsp_shard_row_slices", "bmsp_comm_info", "bmsp_comm_free", "bmsp_spgemm_sharded", "bmsp_spmv_sharded",
+    "bmsp_comm_unique_id", "bmsp_comm_init", "bmsp_comm_init_from_env", "bmsp_comm_init_loopback", "bmsp_shard_layout", "bmsp_shard_row_slices", "bmsp_comm_info", "bmsp_comm_free", "bmsp_spgemm_sharded", "bmsp_spgemm_sharded_ex", "bmsp_spmv_sharded",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
     "bmsp_csr_spmv", "bmsp_csr_multiply_host", "bmsp_csr_spmv_host", "bmsp_csr_free",
 ]
@@ -55,7 +55,8 @@ class SpgemmStats(C.Structure):
 
 class ShardStats(C.Structure):
     _fields_ = [("world", C.c_int), ("rank", C.c_int), ("panel_block_row_begin", C.c_int64), ("panel_block_row_end", C.c_int64),
-                ("panel_tasks", C.c_int64), ("exchange_bytes", C.c_int64), ("exchange_us", C.c_double)]
+                ("panel_tasks", C.c_int64), ("exchange_bytes", C.c_int64), ("exchange_us", C.c_double), ("exchange_exposed_us", C.c_double),
+                ("exchange_hidden_frac", C.c_double), ("rounds", C.c_int), ("gathered", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -129,6 +130,7 @@ def lib():
         L.bmsp_comm_info.argtypes = [vp, p(i), p(i)]
         L.bmsp_comm_free.argtypes = [vp]
         L.bmsp_spgemm_sharded.argtypes = [vp, vp, vp, p(vp), i, i, i, vp, p(SpgemmStats), p(ShardStats)]
+        L.bmsp_spgemm_sharded_ex.argtypes = [vp, vp, vp, p(vp), i, i, i, vp, p(SpgemmStats), p(ShardStats), i, i]
         L.bmsp_spmv_sharded.argtypes = [vp, vp, vp, vp, i, vp, p(ShardStats)]
         L.bmsp_csr_from_mtx.argtypes = [C.c_char_p, p(vp)]
         L.bmsp_csr_from_arrays.argtypes = [i, i, i64, vp, vp, vp, p(vp)]
@@ -522,10 +524,12 @@ class Comm:
             pass
 
 
-def spgemm_sharded(comm, A, B, mode=SORT_AUTO, tc_version=5, verbose=False, stream=None):
+def spgemm_sharded(comm, A, B, mode=SORT_AUTO, tc_version=5, verbose=False, stream=None, gather=True, rounds=0):
+    """gather=False: owner keeps (no exchange, the rank's panel of C); rounds: panels per rank whose exchange overlaps the next product (0: library's choice)"""
     h = C.c_void_p()
     st, sh = SpgemmStats(), ShardStats()
-    check(lib().bmsp_spgemm_sharded(comm.h, A.h, B.h, C.byref(h), int(mode), int(tc_version), int(bool(verbose)), stream, C.byref(st), C.byref(sh)))
+    check(lib().bmsp_spgemm_sharded_ex(comm.h, A.h, B.h, C.byref(h), int(mode), int(tc_version), int(bool(verbose)), stream, C.byref(st), C.byref(sh),
+                                       int(bool(gather)), int(rounds)))
     return BmSpMatrix(h.value), st.as_dict(), sh.as_dict()
 
 

@@ -318,7 +318,10 @@ typedef struct {
     int64_t panel_block_row_begin, panel_block_row_end; /* this rank's block-rows of A */
     int64_t panel_tasks;                                /* surviving tasks of this rank's panel (SpGEMM) */
     int64_t exchange_bytes;                             /* bytes every rank holds after the exchange (whole C / whole y) */
-    double exchange_us;                                 /* device time of the exchange on this rank */
+    double exchange_us;                                 /* device time of the exchange on this rank (all rounds) */
+    double exchange_exposed_us;                         /* ... of it, the part after this rank's last panel product had finished (not hidden behind compute) */
+    double exchange_hidden_frac;                        /* 1 - exposed / total: share of the exchange that ran while panels were being multiplied */
+    int rounds, gathered;                               /* rounds of panels per rank; 0 = owner keeps (no exchange: C is this rank's panel) */
 } bmsp_shard_stats;
 
 /* C = A * B with A cut into `world` block-row panels balanced by candidate-task count, B replicated (every rank passes the same A
@@ -326,6 +329,14 @@ typedef struct {
  * slices (an allgatherv without padding or staging copies), offsets re-based in place.  stats = this rank's panel product. */
 int bmsp_spgemm_sharded(bmsp_comm_t c, bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, int verbose,
                         void *stream, bmsp_spgemm_stats *stats, bmsp_shard_stats *shard);
+/* The same with its two knobs.  gather = 1: as above, in `rounds` rounds per rank (0: the library's choice, 4 when world > 1; BMSP_SHARD_ROUNDS):
+ * A is cut into rounds x world panels, rank r multiplies panels r, world + r, ...; after every round the panel sizes are gathered and the
+ * round's panels are broadcast into their final slices on a second stream while the next round multiplies (shard->exchange_hidden_frac).
+ * gather = 0, "owner keeps" ("If only the owner needs C, skip the gather and report it separately"): world panels, no
+ * exchange; *C is this rank's panel of C (block-rows [panel_block_row_begin, panel_block_row_end), global keys) -- the loopback
+ * communicator owns every panel and returns them concatenated. */
+int bmsp_spgemm_sharded_ex(bmsp_comm_t c, bmsp_matrix_t A, bmsp_matrix_t B, bmsp_matrix_t *C, int mode, int tc_version, int verbose,
+                           void *stream, bmsp_spgemm_stats *stats, bmsp_shard_stats *shard, int gather, int rounds);
 /* u = A * v with A cut into block-row panels balanced by stored values, v replicated; every rank sweeps its panel (writing only its
  * own rows of u), the row slices are exchanged in place and all ranks return the whole u (num_rows entries).  The panel view and its sweep plan are cached on A across calls. */
 int bmsp_spmv_sharded(bmsp_comm_t c, bmsp_matrix_t A, const void *d_v, void *d_u, int variant, void *stream, bmsp_shard_stats *shard);

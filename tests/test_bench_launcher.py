@@ -51,3 +51,13 @@ def test_world_size_must_match_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=60)
     assert r.returncode == 3 and "--gpus 2" in r.stderr and not r.stdout.strip()
+
+
+def test_suitesparse_dimensions_are_asserted():
+    """--mtx-dir: a file named like a BASELINE matrix must have its SuiteSparse dimensions -- a stand-in cannot pass"""
+    ok = {"num_rows": 130228, "num_cols": 130228, "nnz": 2032536}
+    bench.assert_suitesparse_dims("/data/cage12.mtx", ok)
+    with pytest.raises(AssertionError):
+        bench.assert_suitesparse_dims("/data/cage12.mtx", dict(ok, nnz=2032535))
+    with pytest.raises(AssertionError):
+        bench.assert_suitesparse_dims("/data/webbase-1M.mtx", ok)

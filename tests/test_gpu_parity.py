@@ -1463,11 +1463,22 @@ def test_sharded_operators_loopback(bmsp, P, kind):
         bounds = bmsp.partition_rows(A, Bt, P)
         if kind == "diag" and P == 8:
             assert np.any(np.diff(bounds) == 0), bounds     # the construction's point: panels without a single block-row
-        Cs, st, sh = bmsp.spgemm_sharded(comm, A, Bt, tc_version=tc)
-        assert sh["world"] == P and st["surviving_tasks"] == st0["surviving_tasks"] and st["c_blocks"] == st0["c_blocks"]
-        assert sh["exchange_bytes"] == 24 * whole.block_num + 4 * whole.nnz
-        for x, y in zip(Cs.host_arrays(), whole.host_arrays()):
-            np.testing.assert_array_equal(x, y)
+        # rounds = 0: the library's choice (4 rounds of P panels; a round's broadcasts run on a second stream while the next round multiplies);
+        # 1: one panel per rank, exchanged at the end (round 3's form); 3: an odd count; gather = False: owner keeps -- the loopback
+        # communicator owns every panel and returns them concatenated, without an exchange
+        for rounds, gather in ((0, True), (1, True), (3, True), (0, False)):
+            Cs, st, sh = bmsp.spgemm_sharded(comm, A, Bt, tc_version=tc, rounds=rounds, gather=gather)
+            assert sh["world"] == P and st["surviving_tasks"] == st0["surviving_tasks"] and st["c_blocks"] == st0["c_blocks"]
+            if gather:
+                assert sh["exchange_bytes"] == 24 * whole.block_num + 4 * whole.nnz and sh["gathered"] == 1
+                assert sh["rounds"] == (rounds or 4) and 0.0 <= sh["exchange_hidden_frac"] <= 1.0
+                assert sh["exchange_exposed_us"] <= sh["exchange_us"] + 1e-6
+                if rounds == 1:
+                    assert sh["exchange_hidden_frac"] == 0.0  # nothing left to hide behind
+            else:
+                assert sh["gathered"] == 0 and sh["exchange_bytes"] == 0
+            for x, y in zip(Cs.host_arrays(), whole.host_arrays()):
+                np.testing.assert_array_equal(x, y)
     Af = bmsp.BmSpMatrix.from_coo(n_rows, n, r, c, v)
     x = bmsp.DeviceArray.from_host(gen.spmv_x(n, "cusp"))
     for variant in (0, 1):
