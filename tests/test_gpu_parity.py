@@ -1206,31 +1206,40 @@ def test_spgemm_properties_large(bmsp):
         np.testing.assert_allclose(vv, ref.data[order], rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("case", ["2cubes_sphere_like", "cage12_like", "fem_like_27pt"])
+@pytest.mark.parametrize("case", ["2cubes_sphere_like", "cage12_like", "fem_like_27pt", "rmat16"])
 def test_spgemm_bench_size_properties(bmsp, oracle, case):
     """the SpGEMM bench workloads at their full BASELINE.json sizes, through size-independent properties: the three sort
     modes give bit-identical C (V15 numerics); C's pattern is scipy's pattern product; C*1 == A*(A*1) through the SpMV; the fp16
     MFMA product agrees with the fp32 one within the stated fp16 tolerance.  `fem_like_27pt` is the very workload bench.py times for
     configs[2] (fem_like(47, "27pt"): 24.7 M surviving tasks, 14 per C tile -- the regime of the direct / strip block-MAC kernels and of
     the read-back-free register sort); for it the oracle runs once at full size too (about a minute of host time): stage counters, C
-    structure and the fp32 V15 values bit for bit."""
+    structure and the fp32 V15 values bit for bit.  Round 4: the oracle also runs at full size for `cage12_like` (configs[3]: the row-merge
+    TASK-LIST mode, which small inputs do not reach by themselves) -- fp32 V15 bit for bit, and the fp16 tc_version 4 product: structure bit
+    for bit, values within the stated fp16 tolerance of the oracle's exact-product accumulation.  `rmat16` (R-MAT 2^16 x 8: the
+    column-window passes, 1.46e8 candidate pairs, hub block-rows of 3000 tiles of A and 7000 of C) is compared with the pipeline (sort
+    mode 2) on the same handles, every array bit for bit; the oracle pins both on smaller hub inputs (test_spgemm_rowwindow_path)."""
     import scipy.sparse as sp
     from pybmsp import gen
     n, _, r, c, v = {"2cubes_sphere_like": lambda: gen.banded(101492, 8), "cage12_like": lambda: gen.cage_like(130228, 15.6),
-                     "fem_like_27pt": lambda: gen.fem_like(47, "27pt")}[case]()
+                     "fem_like_27pt": lambda: gen.fem_like(47, "27pt"), "rmat16": lambda: gen.rmat(16, 8)}[case]()
+    with_oracle = case in ("fem_like_27pt", "cage12_like")  # (rmat16: 2.5 minutes of oracle per run -- it is compared with the pipeline, bit for bit, below)
     v = np.round(np.asarray(v) * 64) / 64          # exactly representable in fp16 and fp32
     A = bmsp.BmSpMatrix.from_coo(n, n, r, c, v)
     At = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True)
     ref, st0 = bmsp.spgemm(A, At, mode=0, tc_version=5)
     ref_arrays = ref.host_arrays()
-    if case == "fem_like_27pt":
+    if case == "cage12_like":
+        assert st0["sort_path"] == 2 and st0["mac_variant"] != 3, st0   # the row-merge task-list mode
+    if case == "rmat16":
+        assert st0["sort_path"] == 3, st0                               # the column-window passes
+    if with_oracle:
         oc, ost = oracle.spgemm(oracle.bmsp_from_coo(oracle.Coo(n, n, r, c, v), oracle.F32, False),
                                 oracle.bmsp_from_coo(oracle.Coo(n, n, r, c, v), oracle.F32, True))
         assert (st0["task_list_size"], st0["bmp_reduction"], st0["surviving_tasks"], st0["c_blocks"], st0["c_nnz"]) == \
                (ost["task_list_size"], ost["bmp_reduction"], ost["surviving_tasks"], ost["c_blocks"], ost["c_nnz"])
         util.assert_bmsp_equal_exact(oc, *ref_arrays, np.float32)
         del oc
-    for mode in (1, 2):
+    for mode in ((1, 2) if case != "rmat16" else (2,)):
         Cm, st = bmsp.spgemm(A, At, mode=mode, tc_version=5)
         assert (st["task_list_size"], st["surviving_tasks"], st["c_blocks"], st["c_nnz"]) == \
                (st0["task_list_size"], st0["surviving_tasks"], st0["c_blocks"], st0["c_nnz"])
@@ -1238,7 +1247,8 @@ def test_spgemm_bench_size_properties(bmsp, oracle, case):
             np.testing.assert_array_equal(x, y)
         del Cm
     S = sp.coo_matrix((np.ones(r.size), (r, c)), shape=(n, n)).tocsr()
-    assert st0["c_nnz"] == (S @ S).nnz
+    if case != "rmat16":  # (a 1.1e9-entry pattern product on the host: the oracle above has pinned the structure)
+        assert st0["c_nnz"] == (S @ S).nnz
     ones = bmsp.DeviceArray.from_host(np.ones(n, np.float32))
     a1 = bmsp.spmv(A, ones)
     y_chain = bmsp.spmv(A, a1).to_host().astype(np.float64)
@@ -1254,6 +1264,14 @@ def test_spgemm_bench_size_properties(bmsp, oracle, case):
     np.testing.assert_array_equal(kh, ref_arrays[0]); np.testing.assert_array_equal(bh, ref_arrays[1]); np.testing.assert_array_equal(oh, ref_arrays[2])
     y_h = bmsp.spmv(Ch, ones).to_host().astype(np.float64)
     assert np.all(np.abs(y_h - y_prod) <= 2.0 ** -10 * mag + 1e-6)
+    if with_oracle and case != "fem_like_27pt":
+        # the matrix-core product against the oracle's own exact-product accumulation (multiplyV11..V14's numerics, SPGEMM.cu:294-417)
+        och, osth = oracle.spgemm(oracle.bmsp_from_coo(oracle.Coo(n, n, r, c, v), oracle.F16, False),
+                                  oracle.bmsp_from_coo(oracle.Coo(n, n, r, c, v), oracle.F16, True), exact_products=True)
+        assert (sth["task_list_size"], sth["surviving_tasks"], sth["c_blocks"], sth["c_nnz"]) == \
+               (osth["task_list_size"], osth["surviving_tasks"], osth["c_blocks"], osth["c_nnz"])
+        np.testing.assert_array_equal(kh, och.keys); np.testing.assert_array_equal(bh, och.bmps); np.testing.assert_array_equal(oh, och.offsets)
+        np.testing.assert_allclose(vh.astype(np.float64), och.values, rtol=2e-3, atol=1e-6)
 
 
 def _segsort_cuts(shape, rng, n):
