@@ -48,6 +48,7 @@ def parse(argv=None):
     ap.add_argument("--skip-spgemm", action="store_true")
     ap.add_argument("--skip-structures", action="store_true", help="skip the banded SpMV structures")
     ap.add_argument("--skip-vendor", action="store_true", help="skip the rocSPARSE comparison column")
+    ap.add_argument("--skip-cli", action="store_true", help="skip the run of the drop-in executable on the SpGEMM workloads")
     ap.add_argument("--skip-rmat22", action="store_true", help="skip the scale-22 R-MAT product (configs[4] on one GPU: ~40 s of generation + build)")
     ap.add_argument("--only-spgemm", default="", help="experiment: run only the SpGEMM case whose tag contains this (fem | cage | ceiling)")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="bound on the CPU-baseline work, all legs together")
@@ -530,6 +531,7 @@ def bench_spgemm(B, gen, np, args):
         if tag == "rmat22" and args.skip_rmat22 and not args.only_spgemm:
             continue
         dtype = getattr(B, dtn)
+        cli = None
         path = os.path.join(args.mtx_dir, fname) if (args.mtx_dir and fname) else ""
         if path and os.path.exists(path):
             A = B.BmSpMatrix.from_mtx(path, False, dtype)
@@ -540,6 +542,12 @@ def bench_spgemm(B, gen, np, args):
             n, _, r, c, v = mk(gen)
             A = B.BmSpMatrix.from_coo(n, n, r, c, v, dtype=dtype)
             At = B.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=dtype)
+            cli = None
+            if tag in ("fem", "cage") and not args.skip_cli:
+                try:
+                    cli = cli_execution(np, (n, n, r, c, v), 5 if tag == "fem" else 4)
+                except Exception as e:  # an extra: never lose the line over it
+                    cli = {"error": "%s: %s" % (type(e).__name__, e)}
             del r, c, v
         info = A.info()
         # operand preparation (block records, dense tile copies, block-row pointers and row maxima of both operands): built once per
@@ -614,7 +622,7 @@ def bench_spgemm(B, gen, np, args):
                     "tasks_per_c_block": round(best["surviving_tasks"] / max(1, best["c_blocks"]), 2),
                     "c_nnz": best["c_nnz"], "scalar_products": int(P), "total_ms": round(t_total * 1e3, 3), "timing": "median of %d products (device time of the whole call)" % len(runs),
                     "wall_ms": round(best["wall_ms"], 3), "prepare_ms": round(prepare_ms, 3), "first_call_ms": round(first_call_ms, 3),
-                    "total_with_prepare_ms": round(t_total * 1e3 + prepare_ms, 3), "numeric_only": numeric_ms,
+                    "total_with_prepare_ms": round(t_total * 1e3 + prepare_ms, 3), "numeric_only": numeric_ms, "cli": cli,
                     "prepare_note": "prepare = bmsp_matrix_prepare of both operands (host wall time); first_call = the first product after it (cold pool)",
                     "gflops": round(2.0 * P / t_total / 1e9, 2),
                     "gflops_with_prepare": round(2.0 * P / (t_total + prepare_ms * 1e-3) / 1e9, 2),
@@ -626,6 +634,33 @@ def bench_spgemm(B, gen, np, args):
         del A, At
         B.check(B.lib().bmsp_trim_pool())
     return res
+
+
+def cli_execution(np, coo, tc_version=5):
+    """what a user of the drop-in executable sees: the workload written as MatrixMarket, `bmsparse_spgemm_float folder A A
+    0 <tc_version> 0` run on it -- fp16 operands, as the reference's main builds them (src/bmSparse_SPGEMM.cu:1261-1262) -- and its own
+    `bmSparse execution` bracket (ONE product in a fresh process, cold pool, :1274-1280) parsed from stdout."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(REPO, "bmsparse_spgemm_float")
+    if not os.path.exists(exe):
+        return {"error": "bmsparse_spgemm_float not built"}
+    n, _, r, c, v = coo
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "A.mtx")
+        import pandas as pd
+        with open(path, "w") as f:
+            f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (n, n, r.size))
+        pd.DataFrame({"r": np.asarray(r, dtype=np.int64) + 1, "c": np.asarray(c, dtype=np.int64) + 1, "v": np.asarray(v, dtype=np.float64)}).to_csv(
+            path, sep=" ", header=False, index=False, mode="a", float_format="%.9g")
+        out = subprocess.run([exe, d, "A", "A", "0", str(tc_version), "0"], capture_output=True, text=True, timeout=120)
+    if out.returncode != 0:
+        return {"error": (out.stderr or out.stdout)[-200:]}
+    us = {k: int(m.group(1)) for k, pat in (("load_us", r"Loading matrices from disk BMSP: (\d+)"), ("execution_us", r"bmSparse execution: (\d+)"),
+                                            ("c_blocks", r"C blocks: (\d+)"), ("c_nnz", r"C nnz: (\d+)")) for m in [re.search(pat, out.stdout)] if m}
+    us["command"] = "bmsparse_spgemm_float <dir> A A 0 %d 0 (fp16 operands, ONE product in a fresh process)" % tc_version
+    return us
 
 
 def vendor_column(np, gen, wl, eff_bytes, args):

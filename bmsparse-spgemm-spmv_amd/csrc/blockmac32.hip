@@ -605,3 +605,5 @@ int mfma32_selftest(hipStream_t st)
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(blockmac32)

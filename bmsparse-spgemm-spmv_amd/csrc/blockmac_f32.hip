@@ -292,3 +292,5 @@ bool launch_mac_f32_mfma(const uint64_t *tasks, uint64_t n_tasks, const uint32_t
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(blockmac_f32)

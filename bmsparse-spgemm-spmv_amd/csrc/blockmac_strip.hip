@@ -581,8 +581,7 @@ void ensure_finite_flag(bmsp_matrix_s *m, hipStream_t st)
     device_max_sum(ExpMaxF32{(const uint32_t *)m->values + base}, n, mx.p, (unsigned long long *)nullptr, st);
     device_max_sum(ExpMinF32{(const uint32_t *)m->values + base}, n, mx.p + 1, (unsigned long long *)nullptr, st);
     unsigned long long h[2];
-    BMSP_HIP(hipMemcpyAsync(h, mx.p, 16, hipMemcpyDeviceToHost, st));
-    BMSP_HIP(hipStreamSynchronize(st));
+    read_back_bytes(h, mx.p, 16, st);
     m->f32_exp_max = (int)h[0];
     m->f32_exp_min = h[1] ? 255 - (int)h[1] : 255;  // no non-zero value: nothing can underflow
     m->values_finite = h[0] == 255ull ? 0 : 1;
@@ -683,3 +682,5 @@ void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipS
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(blockmac_strip)

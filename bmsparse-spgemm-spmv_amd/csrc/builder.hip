@@ -737,9 +737,9 @@ void matrix_to_coo_host(bmsp_matrix_s *m, int *rows, int *cols, double *vals, hi
     DevBuf<double> v(n);
     matrix_to_coo_device(m, rc.p, v.p, st);
     std::vector<uint64_t> hk(n);
-    BMSP_HIP(hipMemcpyAsync(hk.data(), rc.p, 8 * n, hipMemcpyDeviceToHost, st));
-    BMSP_HIP(hipMemcpyAsync(vals, v.p, 8 * n, hipMemcpyDeviceToHost, st));
     BMSP_HIP(hipStreamSynchronize(st));
+    copy_d2h_staged(hk.data(), rc.p, 8 * n);
+    copy_d2h_staged(vals, v.p, 8 * n);
     for (uint64_t i = 0; i < n; i++) {
         rows[i] = (int)(hk[i] >> 32);
         cols[i] = (int)(hk[i] & 0xffffffffull);
@@ -897,3 +897,5 @@ bmsp_matrix_s *build_from_device_csr(int num_rows, int num_cols, int64_t nnz, co
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(builder)

@@ -75,9 +75,9 @@ static bmsp_matrix_s *build_from_host_coo(int num_rows, int num_cols, int64_t nn
     DevBuf<int> dr(n), dc(n);
     DevBuf<double> dv(n);
     if (n) {
-        BMSP_HIP(hipMemcpy(dr.p, rows, sizeof(int) * n, hipMemcpyHostToDevice));
-        BMSP_HIP(hipMemcpy(dc.p, cols, sizeof(int) * n, hipMemcpyHostToDevice));
-        BMSP_HIP(hipMemcpy(dv.p, vals, sizeof(double) * n, hipMemcpyHostToDevice));
+        copy_h2d_staged(dr.p, rows, sizeof(int) * n);
+        copy_h2d_staged(dc.p, cols, sizeof(int) * n);
+        copy_h2d_staged(dv.p, vals, sizeof(double) * n);
     }
     return build_from_device_coo(num_rows, num_cols, nnz, dr.p, dc.p, dv.p, transposed, dtype, nullptr);
 }
@@ -116,13 +116,13 @@ int bmsp_free(void *dptr)
 int bmsp_memcpy_h2d(void *dst, const void *src, size_t bytes)
 {
     BMSP_API_BEGIN
-    if (bytes) BMSP_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    copy_h2d_staged(dst, src, bytes);
     BMSP_API_END
 }
 int bmsp_memcpy_d2h(void *dst, const void *src, size_t bytes)
 {
     BMSP_API_BEGIN
-    if (bytes) BMSP_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    copy_d2h_staged(dst, src, bytes);
     BMSP_API_END
 }
 int bmsp_memcpy_d2d(void *dst, const void *src, size_t bytes)
@@ -183,6 +183,7 @@ int bmsp_event_destroy(void *event)
 int bmsp_matrix_from_mtx(const char *path, int transposed, bmsp_dtype dtype, bmsp_matrix_t *out)
 {
     BMSP_API_BEGIN
+    load_kernels();
     need(path, "path");
     need(out, "out");
     HostCoo coo;
@@ -196,6 +197,7 @@ int bmsp_matrix_from_coo(int num_rows, int num_cols, int64_t nnz, const int *row
                          bmsp_dtype dtype, bmsp_matrix_t *out)
 {
     BMSP_API_BEGIN
+    load_kernels();
     need(out, "out");
     if (nnz > 0) { need(rows, "rows"); need(cols, "cols"); need(vals, "vals"); }
     *out = build_from_host_coo(num_rows, num_cols, nnz, rows, cols, vals, transposed, dtype);
@@ -206,6 +208,7 @@ int bmsp_matrix_from_coo_device(int num_rows, int num_cols, int64_t nnz, const i
                                 int transposed, bmsp_dtype dtype, void *stream, bmsp_matrix_t *out)
 {
     BMSP_API_BEGIN
+    load_kernels();
     need(out, "out");
     *out = build_from_device_coo(num_rows, num_cols, nnz, d_rows, d_cols, d_vals, transposed, dtype, as_stream(stream));
     BMSP_API_END
@@ -215,6 +218,7 @@ int bmsp_matrix_from_arrays(int num_rows, int num_cols, int64_t block_num, int64
                             uint64_t *d_offsets, void *d_values, bmsp_dtype dtype, int transposed, int ownership, bmsp_matrix_t *out)
 {
     BMSP_API_BEGIN
+    load_kernels();
     need(out, "out");
     if (block_num < 0 || nnz < 0 || num_rows < 0 || num_cols < 0) fail(BMSP_ERR_INVALID, "negative size");
     if (block_num > 0) { need(d_keys, "keys"); need(d_bmps, "bmps"); need(d_offsets, "offsets"); }
@@ -281,7 +285,7 @@ int bmsp_matrix_save(bmsp_matrix_t m, const char *path)
     std::vector<char> buf;
     auto dump = [&](const void *dptr, size_t bytes) {
         buf.resize(bytes);
-        if (bytes) BMSP_HIP(hipMemcpy(buf.data(), dptr, bytes, hipMemcpyDeviceToHost));
+        copy_d2h_staged(buf.data(), dptr, bytes);
         if (bytes && fwrite(buf.data(), 1, bytes, f) != bytes) fail(BMSP_ERR_IO, "short write to '%s'", path);
     };
     if (fwrite(&h, sizeof h, 1, f) != 1) fail(BMSP_ERR_IO, "short write to '%s'", path);
@@ -292,6 +296,7 @@ int bmsp_matrix_save(bmsp_matrix_t m, const char *path)
 int bmsp_matrix_load(const char *path, bmsp_matrix_t *out)
 {
     BMSP_API_BEGIN
+    load_kernels();
     need(path, "path"); need(out, "out");
     FILE *f = fopen(path, "rb");
     if (!f) fail(BMSP_ERR_IO, "cannot open '%s'", path);
@@ -308,7 +313,7 @@ int bmsp_matrix_load(const char *path, bmsp_matrix_t *out)
         *dptr = pool_alloc(bytes ? bytes : 8);
         buf.resize(bytes);
         if (bytes && fread(buf.data(), 1, bytes, f) != bytes) fail(BMSP_ERR_IO, "'%s' is truncated", path);
-        if (bytes) BMSP_HIP(hipMemcpy(*dptr, buf.data(), bytes, hipMemcpyHostToDevice));
+        copy_h2d_staged(*dptr, buf.data(), bytes);
     };
     slurp((void **)&m->keys, 8 * nb); slurp((void **)&m->bmps, 8 * nb); slurp((void **)&m->offsets, 8 * (nb + 1));
     slurp(&m->values, es * (size_t)h.nnz);
@@ -410,6 +415,7 @@ int bmsp_matrix_from_csr_device(int num_rows, int num_cols, int64_t nnz, const i
                                 int transposed, bmsp_dtype dtype, void *stream, bmsp_matrix_t *out)
 {
     BMSP_API_BEGIN
+    load_kernels();
     need(out, "out"); need(d_row_offsets, "row_offsets");
     if (num_rows < 0 || num_cols < 0 || nnz < 0) fail(BMSP_ERR_INVALID, "negative size");
     if (nnz) { need(d_cols, "cols"); need(d_vals, "vals"); }
@@ -782,9 +788,9 @@ int bmsp_csr_spmv(bmsp_csr_t A, const float *x, float *y)
     need(A, "A"); need(x, "x"); need(y, "y");
     bmsp_matrix_s *dA = csr_device_form(A, 0);
     DevBuf<float> dx((size_t)A->num_cols), dy((size_t)A->num_rows);
-    if (A->num_cols) BMSP_HIP(hipMemcpy(dx.p, x, 4 * (size_t)A->num_cols, hipMemcpyHostToDevice));
+    copy_h2d_staged(dx.p, x, 4 * (size_t)A->num_cols);
     spmv(dA, dx.p, dy.p, BMSP_SPMV_DEFAULT, nullptr);
-    if (A->num_rows) BMSP_HIP(hipMemcpy(y, dy.p, 4 * (size_t)A->num_rows, hipMemcpyDeviceToHost));
+    copy_d2h_staged(y, dy.p, 4 * (size_t)A->num_rows);
     BMSP_API_END
 }
 

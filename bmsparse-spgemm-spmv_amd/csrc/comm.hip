@@ -478,10 +478,10 @@ static void spmv_bounds(bmsp_matrix_s *A, int P, std::vector<int64_t> &bounds, h
     ensure_rowptr(A, st);
     const int64_t nbr = A->num_block_rows();
     std::vector<uint32_t> rp((size_t)nbr + 1);
-    BMSP_HIP(hipMemcpyAsync(rp.data(), A->rowptr, 4 * rp.size(), hipMemcpyDeviceToHost, st));
     std::vector<uint64_t> off((size_t)A->block_num + 1);
-    BMSP_HIP(hipMemcpyAsync(off.data(), A->offsets, 8 * off.size(), hipMemcpyDeviceToHost, st));
     BMSP_HIP(hipStreamSynchronize(st));
+    copy_d2h_staged(rp.data(), A->rowptr, 4 * rp.size());
+    copy_d2h_staged(off.data(), A->offsets, 8 * off.size());
     const uint64_t base = off[rp[0]], total = off[rp[(size_t)nbr]] - base;
     bounds.assign((size_t)P + 1, 0);
     int64_t r = 0;
@@ -546,3 +546,5 @@ void spmv_sharded(bmsp_comm_s *c, bmsp_matrix_s *A, const void *x, void *y, int 
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(comm)

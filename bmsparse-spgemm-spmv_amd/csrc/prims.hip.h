@@ -11,6 +11,7 @@
 #include "runtime.h"
 #include "bmsp_bits.h"
 #include <chrono>
+#include <cstring>
 
 namespace bmsp {
 
@@ -521,13 +522,31 @@ struct PtrOutTotal {
     }
 };
 
+// one scalar from device memory, through a PINNED host slot: a device-to-host copy into pageable memory makes the runtime set up its staging
+// buffers the first time a process does one -- 21 ms inside the first product of the drop-in executable (measured: T_1's row statistics)
 template <typename T>
 T read_back(const T *dptr, hipStream_t st)
 {
-    T v;
-    BMSP_HIP(hipMemcpyAsync(&v, dptr, sizeof(T), hipMemcpyDeviceToHost, st));
-    BMSP_HIP(hipStreamSynchronize(st));
+    static_assert(sizeof(T) <= 64, "a host slot holds 64 bytes");
+    T *slot = static_cast<T *>(host_slot_acquire());
+    hipError_t e = hipMemcpyAsync(slot, dptr, sizeof(T), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    const T v = *slot;
+    host_slot_release(slot);
+    if (e != hipSuccess) fail(BMSP_ERR_HIP, "read_back failed: %s", hipGetErrorString(e));
     return v;
+}
+
+// up to 64 bytes from device memory through a pinned host slot (see read_back)
+inline void read_back_bytes(void *host, const void *dptr, size_t bytes, hipStream_t st)
+{
+    if (bytes > 64) fail(BMSP_ERR_INVALID, "read_back_bytes: a host slot holds 64 bytes");
+    void *slot = host_slot_acquire();
+    hipError_t e = hipMemcpyAsync(slot, dptr, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    memcpy(host, slot, bytes);
+    host_slot_release(slot);
+    if (e != hipSuccess) fail(BMSP_ERR_HIP, "read_back failed: %s", hipGetErrorString(e));
 }
 
 }  // namespace bmsp

@@ -775,3 +775,5 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(rowmerge)

@@ -627,3 +627,5 @@ bool rowmerge_windowed(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(rowwindow)

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdarg>
+#include <chrono>
 #include <stdexcept>
 #include <string>
 #include "../../include/bmsp.h"
@@ -92,6 +93,7 @@ struct StageTimer {
     static constexpr int kMax = 24;
     hipEvent_t ev[kMax];
     int stage_of[kMax];
+    double host_us[kMax];  // host clock at the mark (BMSP_HOST_TIMES=1 prints them: where the HOST spends a call)
     int n = 0;
     StageTimer(hipStream_t s, bool enable) : st(s), on(enable) {}
     ~StageTimer()
@@ -105,7 +107,16 @@ struct StageTimer {
         BMSP_HIP(hipEventCreate(&ev[n]));
         BMSP_HIP(hipEventRecord(ev[n], st));
         stage_of[n] = stage;
+        host_us[n] = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3;
         n++;
+    }
+    void print_host_times(const char *what) const
+    {
+        if (!on || n < 1) return;
+        const double now = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3;
+        fprintf(stderr, "[host times] %s:", what);
+        for (int i = 1; i < n; i++) fprintf(stderr, " ->%d %.0f", stage_of[i], host_us[i] - host_us[i - 1]);
+        fprintf(stderr, " | since last mark %.0f us\n", now - host_us[n - 1]);
     }
     // adds every interval to t_us[stage]; returns the time between the first and the last mark
     double collect(double *t_us)
@@ -122,6 +133,23 @@ struct StageTimer {
         return (double)tot * 1000.0;
     }
 };
+
+// Code objects are loaded lazily, on the first launch of a kernel of their translation unit (0.1 - 0.3 ms each: the first SpMV prepare
+// of a process took 2.1 ms, the second 0.16 ms).  Every .hip file with kernels defines an empty one; load_kernels() launches them all
+// once per device from the constructors of a matrix (the reference's cudaFree(0) warm-up at the top of main, src/bmSparse_SPMV.cu:237,
+// serves the same purpose): what the reference's "bmSparse execution" brackets then starts with the code resident.
+#define BMSP_DEFINE_WARM(name)                                                                                        \
+    namespace bmsp {                                                                                                  \
+    __global__ void warm_kernel_##name() {}                                                                           \
+    void warm_##name(hipStream_t st) { hipLaunchKernelGGL(warm_kernel_##name, dim3(1), dim3(1), 0, st); }             \
+    }
+void load_kernels();
+// Host <-> device copies of caller-owned (pageable) memory, staged through the library's own pinned buffers.  A plain hipMemcpy makes the
+// runtime register the caller's pages with the driver; when the caller frees them (the MatrixMarket parser's triples: 100 MB), the driver's
+// MMU notifier evicts the process's GPU queues and restores them tens of milliseconds later -- the first product of the drop-in
+// executable waited 25 ms for that (measured; a 50 ms sleep before the product made it 3 ms).
+void copy_h2d_staged(void *dst, const void *src, size_t bytes);
+void copy_d2h_staged(void *dst, const void *src, size_t bytes);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

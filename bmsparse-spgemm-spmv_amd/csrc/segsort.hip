@@ -661,8 +661,7 @@ bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *se
         BMSP_HIP(hipMemsetAsync(scal.p, 0, 12, st));
         device_exclusive_scan<uint32_t>(PiecesIn{cls, cap}, PiecesOut{cls, cap, segs2.p, scal.p, scal.p + 1, scal.p + 2}, (uint64_t)nseg + 1, st);
         uint32_t hs[3];
-        BMSP_HIP(hipMemcpyAsync(hs, scal.p, 12, hipMemcpyDeviceToHost, st));
-        BMSP_HIP(hipStreamSynchronize(st));
+        read_back_bytes(hs, scal.p, 12, st);
         const uint32_t nseg2 = hs[0], max_len = hs[1];
         const bool all_long = (uint64_t)hs[2] == n;
         if (!segsort_tasks_lds<W>(keys, perm, n, segs2.p, nseg2, jbits, st)) return false;
@@ -772,3 +771,5 @@ bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals,
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(segsort)

@@ -50,8 +50,8 @@ void partition_rows(bmsp_matrix_s *A, bmsp_matrix_s *B, int parts, int64_t *boun
                                     n_a + 1, st);
     device_for_each(RowWork{first_pos.p, A->rowptr, cum.p}, (uint64_t)nbr + 1, st);
     std::vector<uint64_t> h((size_t)nbr + 1);
-    BMSP_HIP(hipMemcpyAsync(h.data(), cum.p, 8 * ((size_t)nbr + 1), hipMemcpyDeviceToHost, st));
     BMSP_HIP(hipStreamSynchronize(st));
+    copy_d2h_staged(h.data(), cum.p, 8 * ((size_t)nbr + 1));  // (through the library's pinned buffers: `h` is freed on return, see runtime.h)
     const uint64_t total = h[(size_t)nbr];
     if (total_out) *total_out = total;
     bounds[0] = 0;
@@ -168,3 +168,5 @@ void spgemm_paneled(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, in
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(shard)

@@ -1026,9 +1026,14 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         C->values = pool_alloc(dtype_size(C->dtype) * (size_t)(c_nnz ? c_nnz : 1));
         return c_nnz;
     };
+    const double host_t0 = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3;
     auto finish = [&]() {
         BMSP_HIP(hipStreamSynchronize(st));  // reference: cudaDeviceSynchronize (:1158)
         segsort_check_violation();
+        if (getenv("BMSP_HOST_TIMES")) {
+            fprintf(stderr, "[host times] spgemm entered %.0f us before the first mark\n", tm.n ? tm.host_us[0] - host_t0 : 0.0);
+            tm.print_host_times("spgemm marks (stage: host us since the previous mark)");
+        }
         S->t_us[0] = tm.collect(S->t_us);
         S->t_us[5] += S->t_us[8];  // the reference's T_5 includes its "Segmented sort" sub-timer (:1009-1024)
         if (verbose) {
@@ -1371,3 +1376,5 @@ void spgemm_numeric(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(spgemm)

@@ -477,3 +477,5 @@ void spmm(bmsp_matrix_s *A, const void *X, int64_t ldx, void *Y, int64_t ldy, in
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(spmm)

@@ -1182,8 +1182,8 @@ void spmv_launch_info(bmsp_matrix_s *A, int variant, hipStream_t st, char *kerne
                 name = cached ? (red == kAtomic ? "spmv_vstream_kernel<kCached, kAtomic>" : "spmv_vstream_kernel<kCached, kSorted>")
                               : (red == kAtomic ? "spmv_vstream_kernel<kDecode, kAtomic>" : "spmv_vstream_kernel<kDecode, kSorted>");
                 std::vector<SweepItem> items((size_t)n_items);
-                if (n_items) BMSP_HIP(hipMemcpyAsync(items.data(), plan_items(A), sizeof(SweepItem) * (size_t)n_items, hipMemcpyDeviceToHost, st));
                 BMSP_HIP(hipStreamSynchronize(st));
+                if (n_items) copy_d2h_staged(items.data(), plan_items(A), sizeof(SweepItem) * (size_t)n_items);
                 int64_t multi_tiles = 0, long_items = 0;
                 for (const SweepItem &it : items) {
                     if (!vs_single(it)) multi_tiles += (int64_t)(it.blk_end - it.blk_begin);
@@ -1229,3 +1229,5 @@ void spmv(bmsp_matrix_s *A, const void *v, void *u, int variant, hipStream_t st,
 }
 
 }  // namespace bmsp
+
+BMSP_DEFINE_WARM(spmv)
