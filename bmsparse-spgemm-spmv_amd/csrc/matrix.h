@@ -38,6 +38,7 @@ struct bmsp_matrix_s {
     uint32_t *sym_recs = nullptr;    // right operands: block_num x {bitmap ROW-major (lo, hi), block column, rows the tile uses}: all the column-window passes (rowwindow.hip) read per candidate pair
     // column index of the long block-rows (right operands of the column-window passes): col_index[col_index_row[k] + c / col_index_gran] = first
     // tile of block-row k whose block column is >= c; col_index_row[k] = ~0 for block-rows of at most kIdxMinLen tiles
+    uint32_t *col_mass = nullptr;  // prefix sums of this matrix's tiles per granule of col_index_gran block columns (ceil(cols / gran) + 1 entries): where the column-window passes cut
     uint32_t *col_index = nullptr, *col_index_row = nullptr;
     uint32_t col_index_gran = 0;
     int col_index_tried = 0;
@@ -49,6 +50,7 @@ struct bmsp_matrix_s {
     const void *rm_partner_keys = nullptr;
     int64_t rm_partner_blocks = 0;
     int rm_partner_mode = 0;
+    int64_t rm_partner_cw_hash = 0;  // column-window passes: candidate pairs per hashed window that worked for the pair (0: the default)
     // a product made by bmsp_spgemm_symbolic keeps its sorted task list for bmsp_spgemm_numeric (T_7 alone on new operand values)
     uint64_t *sp_tasks = nullptr;
     uint32_t *sp_task_begin = nullptr, *sp_c_of_wave = nullptr;
@@ -121,6 +123,7 @@ uint64_t ensure_struct_hash(bmsp_matrix_s *m, hipStream_t st);
 void ensure_block_meta(bmsp_matrix_s *m, hipStream_t st);
 void ensure_sym_recs(bmsp_matrix_s *m, hipStream_t st);
 void ensure_col_index(bmsp_matrix_s *m, uint32_t gran, hipStream_t st);
+void ensure_col_mass(bmsp_matrix_s *m, uint32_t gran, hipStream_t st);
 constexpr uint32_t kIdxMinLen = 16;
 int tile_product_selftest(hipStream_t st);
 void ensure_dense_tiles(bmsp_matrix_s *m, hipStream_t st);

@@ -804,7 +804,8 @@ def test_spgemm_rowmerge_task_list(oracle, bmsp, monkeypatch, case, dtype, tc):
         np.testing.assert_array_equal(x, z)
 
 
-@pytest.mark.parametrize("case", ["rmat13", "rmat11_narrow", "hub_row_diag", "hub_rmat", "rect_wide", "long_a_rows", "filtered", "cage", "empty"])
+@pytest.mark.parametrize("case", ["rmat13", "rmat11_narrow", "hub_row_diag", "hub_rmat", "rect_wide", "long_a_rows", "filtered", "cage", "empty", "wide_hashed",
+                                  "hash_overflow", "rmat15_wide"])
 @pytest.mark.parametrize("dtype,tc", [(0, 5), (1, 4), (1, 5), (2, 5)])
 def test_spgemm_rowwindow_path(oracle, bmsp, monkeypatch, case, dtype, tc):
     """Column-window passes (rowwindow.hip; round 4): a workgroup per (block-row of A, window of C's block columns), dense tables in LDS,
@@ -854,12 +855,30 @@ def test_spgemm_rowwindow_path(oracle, bmsp, monkeypatch, case, dtype, tc):
         n, _, r, c, v = gen.cage_like(20000, per_row=6.0)
         A = Bc = (n, n, r, c, np.round(v * 64) / 64)
         cand = 256
+    elif case in ("wide_hashed", "hash_overflow"):
+        # B has 40 000 block columns: windows wider than the dense tables -> hashed slots (open addressing, C's key order by an LDS sort).
+        # ~6400 candidate pairs and ~6000 C tiles per block-row.  hash_overflow: cut for 16384 pairs per window, one window would hold twice
+        # what a table takes -- the pass reports it, the host cuts finer and runs it again (three times here) instead of giving up
+        rng = np.random.default_rng(23)
+        m, k, nn = 400, 4000, 320000
+        ra = np.repeat(np.arange(m), 10); ca = rng.integers(0, k, ra.size)
+        rb = np.repeat(np.arange(k), 10); cb = rng.integers(0, nn, rb.size)
+        A = (m, k, ra, ca, rng.integers(1, 4, ra.size).astype(np.float64))
+        Bc = (k, nn, rb, cb, rng.integers(1, 4, rb.size).astype(np.float64))
+        exact = True
+        if case == "hash_overflow":
+            monkeypatch.setenv("BMSP_WIN_CAND_HASH", "16384")
+    elif case == "rmat15_wide":  # a power-law operand wider than the dense tables reach: dense windows over the hub columns, hashed ones over the tail
+        n, _, r, c, v = gen.rmat(15, 4)
+        A = (n, n, r, c, np.round(v * 8) / 8)
+        Bc = (n, 8 * n, r, c * 8, np.round(v * 8) / 8)   # B's columns spread over 32768 block columns
     else:  # empty: A has block-rows without a tile and tiles whose block column has no block-row in B
         A = (100, 64, np.array([0, 3, 90, 91]), np.array([1, 60, 2, 63]), np.array([1.0, 2.0, 3.0, 4.0]))
         Bc = (64, 40, np.array([1, 2, 2]), np.array([0, 39, 17]), np.array([1.0, 1.0, 2.0]))
         exact = True
     if force:
         monkeypatch.setenv("BMSP_SPGEMM_ROWWINDOW", "1")
+        monkeypatch.setenv("BMSP_WIN_THIN", "1")  # (the library leaves products with a handful of pairs per (A tile, window) to the pipeline: taken here all the same)
     if cand:
         monkeypatch.setenv("BMSP_WIN_CAND", str(cand))
     st = check_spgemm(oracle, bmsp, A, Bc, dtype, 0, tc, exact_expected=exact)
