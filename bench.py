@@ -148,10 +148,12 @@ def load_spmv_workload(args):
 
 def profile_value(pattern, key, kernel_sources):
     """(value, stamp) from the newest committed rocprofv3 summary matching profiles/<pattern>.  A counter figure is only quoted while it
-    still describes the kernel that runs: every summary carries the commit it was profiled at (`profiled_at_commit`; written by
-    tools/summarize_*.py) and the figure is DROPPED (None) when `git log` shows that one of the kernel's source files changed after that
-    commit, or when the summary carries no stamp, or when the history is not available (the GPU box gets a snapshot without .git: the
-    stamp is then reported as-is and marked unverified)."""
+    still describes the kernel that runs: every summary carries the sha256 of the kernel sources of the tree it was profiled on
+    (`source_sha256`, tools/source_hash.py run on the GPU box beside the passes) and the figure is DROPPED (None) when one of THIS kernel's
+    source files no longer has that digest in the tree bench.py runs from -- a content check, so it works on the GPU box, which gets a
+    snapshot without .git.  Summaries of earlier rounds carry a commit instead (`profiled_at_commit`): checked against `git log` where a
+    history exists, dropped where it does not."""
+    import hashlib
     import subprocess
     best = None
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", pattern))):
@@ -160,20 +162,31 @@ def profile_value(pattern, key, kernel_sources):
         except Exception:
             continue
         if key in d:
-            best = (d[key], d.get("profiled_at_commit"), os.path.basename(f))
+            best = (d[key], d, os.path.basename(f))
     if best is None:
         return None, None
-    val, commit, fname = best
+    val, d, fname = best
+    digests = d.get("source_sha256")
+    if digests:
+        for src in kernel_sources:
+            try:
+                now = hashlib.sha256(open(os.path.join(REPO, src), "rb").read()).hexdigest()
+            except OSError:
+                now = None
+            if digests.get(src) != now:
+                return None, "%s is stale: %s changed since it was profiled -> not quoted" % (fname, src)
+        return val, "%s (source digests of %s match)" % (fname, ", ".join(os.path.basename(s) for s in kernel_sources))
+    commit = d.get("profiled_at_commit")
     if not commit:
-        return None, "%s: no profiled_at_commit stamp -> not quoted" % fname
+        return None, "%s: neither source digests nor a commit stamp -> not quoted" % fname
     try:
         out = subprocess.run(["git", "-C", REPO, "log", "--oneline", "%s..HEAD" % commit, "--"] + kernel_sources, capture_output=True, text=True, timeout=20)
         if out.returncode != 0:
-            return val, "%s @ %s (history unavailable here: staleness unverified)" % (fname, commit)
+            return None, "%s @ %s: no source digests and no history here -> not quoted" % (fname, commit)
         if out.stdout.strip():
             return None, "%s @ %s is stale: %d later commit(s) touch %s -> not quoted" % (fname, commit, len(out.stdout.strip().splitlines()), ", ".join(kernel_sources))
     except Exception:
-        return val, "%s @ %s (git not runnable here: staleness unverified)" % (fname, commit)
+        return None, "%s @ %s: no source digests and git not runnable here -> not quoted" % (fname, commit)
     return val, "%s @ %s" % (fname, commit)
 
 

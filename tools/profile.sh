@@ -2,6 +2,7 @@
 # rocprofv3 passes for the SpMV bench: kernel trace + stats, then PMC passes (separate runs, no tracing domains mixed in)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
+python3 $GRAFT_REPO_ROOT/tools/source_hash.py > $OUT/source_hash.json
 cd /tmp && export TMPDIR=/tmp
 ARGS="--skip-cpu --skip-spgemm --skip-vendor --steps 100 --warmup 10 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/trace.log 2>&1

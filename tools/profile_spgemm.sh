@@ -3,6 +3,7 @@
 # kernel trace + stats first, then every PMC group in its own run (never combined with a tracing domain).
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; CASE=${2:-cage}; EXTRA=$3   # arg 3: --fp32 for the fp32 V15 configuration
 mkdir -p $OUT
+python3 $GRAFT_REPO_ROOT/tools/source_hash.py > $OUT/source_hash.json
 cd /tmp && export TMPDIR=/tmp
 P=$GRAFT_REPO_ROOT/tools/spgemm_stages.py
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $P $CASE --quick $EXTRA > $OUT/trace.log 2>&1

@@ -59,7 +59,11 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             a = agg[row["Counter_Name"]]; a[0] += 1; a[1] += float(row["Counter_Value"])
     for c, (n, sm) in agg.items(): tot[c] = sm / n
 if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
-    tr = {"kernel": kern, "profiled_at_commit": profiled_commit(src), "fetch_size_kib": tot["FETCH_SIZE"], "write_size_kib": tot["WRITE_SIZE"],
+    try:
+        src_hash = json.load(open(os.path.join(src, "source_hash.json")))  # tools/source_hash.py, run on the box beside the passes
+    except (OSError, ValueError):
+        src_hash = None
+    tr = {"kernel": kern, "profiled_at_commit": profiled_commit(src), "source_sha256": src_hash, "fetch_size_kib": tot["FETCH_SIZE"], "write_size_kib": tot["WRITE_SIZE"],
           "traffic_bytes_per_launch": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024),
           "method": "2*FETCH_SIZE + WRITE_SIZE (KiB), separate --pmc passes; factor 2 calibrated by experiments/fetch_calib.hip"}
     json.dump(tr, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
