@@ -202,8 +202,11 @@ int g_f32_chain_ok = -1;  // -1 not tested yet, 0 differs, 1 the MFMA is the fma
 
 }  // namespace
 
-// number of result elements (of 16 x 16 x several trials) that differ from the host's k-ascending fmaf chain
-int mfma_f32_selftest(hipStream_t st)
+// number of result elements (of 16 x 16 x several trials) that differ from the host's k-ascending fmaf chain.  cancel = false: operands of
+// ordinary magnitude (every product and every partial sum a normal number).  cancel = true: every PRODUCT is a normal number (~2^-123) but
+// the signs alternate, so the partial sums cancel into the subnormal range -- the corner the strip kernel's exponent guard has to know about
+// ("a*b + c < 2^-126 while both products are normal").
+int mfma_f32_selftest(hipStream_t st, bool cancel)
 {
     DevBuf<float> da(128), db(128), dc(256), dd(256);
     int bad = 0;
@@ -213,12 +216,23 @@ int mfma_f32_selftest(hipStream_t st)
         const int e = (int)((s >> 40) % 9) - 4;
         return (float)std::ldexp((double)((int64_t)(s & 0xffffff) - 0x800000) / 8388608.0, e);
     };
+    auto near_one = [&]() {  // 1 + a few units in the last places
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        return 1.0 + (double)(s & 0xff) / 8388608.0;
+    };
     for (int trial = 0; trial < 8; trial++) {
         float a[128], b[128], c[256], d[256];
-        for (float &x : a) x = rnd();
-        for (float &x : b) x = rnd();
-        for (float &x : c) x = trial == 0 ? 0.f : rnd();
-        if (trial == 1) c[5] = -0.0f;
+        if (!cancel) {
+            for (float &x : a) x = rnd();
+            for (float &x : b) x = rnd();
+            for (float &x : c) x = trial == 0 ? 0.f : rnd();
+            if (trial == 1) c[5] = -0.0f;
+        } else {
+            for (int i = 0; i < 16; i++)
+                for (int k = 0; k < 8; k++) a[i * 8 + k] = (float)std::ldexp(((k & 1) ? -1.0 : 1.0) * near_one(), -60 - (trial & 1));
+            for (float &x : b) x = (float)std::ldexp(near_one(), -63);
+            for (float &x : c) x = trial < 2 ? 0.f : (float)std::ldexp(near_one() - 1.0, -126 - (trial & 3));  // zero, or subnormal starts
+        }
         BMSP_HIP(hipMemcpyAsync(da.p, a, sizeof a, hipMemcpyHostToDevice, st));
         BMSP_HIP(hipMemcpyAsync(db.p, b, sizeof b, hipMemcpyHostToDevice, st));
         BMSP_HIP(hipMemcpyAsync(dc.p, c, sizeof c, hipMemcpyHostToDevice, st));
@@ -236,6 +250,16 @@ int mfma_f32_selftest(hipStream_t st)
     return bad;
 }
 
+int g_f32_cancel_ok = -1;  // 1: the matrix pipe is the fmaf chain also where normal products cancel into subnormal sums
+// smallest sum of the operands' smallest biased exponents the fp32 matrix-core kernels accept: 128 = every product a normal number;
+// where cancellation into subnormals is NOT the fmaf chain's, 46 more bits of room (the products of a C entry cannot cancel below
+// 2^-126 unless they lose more than two mantissas' worth of bits)
+int mac_f32_exp_floor(hipStream_t st)
+{
+    if (g_f32_cancel_ok < 0) g_f32_cancel_ok = mfma_f32_selftest(st, true) == 0 ? 1 : 0;
+    return g_f32_cancel_ok == 1 ? 128 : 128 + 46;
+}
+
 // fp32 matrices: every tile expanded to 64 floats in MFMA lane order (256 B per block), cached per matrix like the other operand forms
 void ensure_lane_tiles(bmsp_matrix_s *m, hipStream_t st)
 {
@@ -247,7 +271,7 @@ void ensure_lane_tiles(bmsp_matrix_s *m, hipStream_t st)
 
 bool mac_f32_mfma_usable(hipStream_t st)
 {
-    if (g_f32_chain_ok < 0) g_f32_chain_ok = mfma_f32_selftest(st) == 0 ? 1 : 0;
+    if (g_f32_chain_ok < 0) g_f32_chain_ok = mfma_f32_selftest(st, false) == 0 ? 1 : 0;
     return g_f32_chain_ok == 1;
 }
 
@@ -267,7 +291,7 @@ bool launch_mac_f32_mfma(const uint64_t *tasks, uint64_t n_tasks, const uint32_t
     // (the instruction is the fmaf chain only while every product is a normal number: see mac_strip_operands_ok)
     ensure_finite_flag(A, st);
     ensure_finite_flag(B, st);
-    if (A->values_finite != 1 || B->values_finite != 1 || A->f32_exp_min + B->f32_exp_min < 128 || A->f32_exp_max + B->f32_exp_max > 354) return false;
+    if (A->values_finite != 1 || B->values_finite != 1 || A->f32_exp_min + B->f32_exp_min < mac_f32_exp_floor(st) || A->f32_exp_max + B->f32_exp_max > 354) return false;
     ensure_lane_tiles(A, st);
     ensure_lane_tiles(B, st);
     MacF32Args g{};

@@ -600,7 +600,7 @@ bool mac_strip_operands_ok(bmsp_matrix_s *A, bmsp_matrix_s *B, hipStream_t st)
         // matrix pipe's rounding is not the fmaf chain's, and V15's vector-ALU kernel (task-list mode or the pipeline) takes the product
         ensure_finite_flag(A, st);
         ensure_finite_flag(B, st);
-        if (A->f32_exp_min + B->f32_exp_min < 128 || A->f32_exp_max + B->f32_exp_max > 254 + 100) return false;
+        if (A->f32_exp_min + B->f32_exp_min < mac_f32_exp_floor(st) || A->f32_exp_max + B->f32_exp_max > 254 + 100) return false;
     } else {
         return false;
     }

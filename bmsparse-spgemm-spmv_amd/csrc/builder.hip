@@ -398,7 +398,8 @@ void invalidate_matrix(bmsp_matrix_s *m, int structure_changed)
     if (!structure_changed) return;
     pool_free(m->rowptr); m->rowptr = nullptr; m->rowptr_rows = 0; m->max_row_blocks = -1;
     m->struct_hash = 0; m->sp_a_hash = 0; m->sp_b_hash = 0;
-    m->rm_partner_keys = nullptr; m->rm_partner_blocks = 0; m->rm_partner_mode = 0;
+    m->rm_partner_uid = 0; m->rm_partner_blocks = 0; m->rm_partner_mode = 0; m->rm_partner_cw_hash = 0;
+    m->uid = next_matrix_uid();  // what other matrices remembered about this one's old structure no longer applies
     pool_free(m->sp_tasks); pool_free(m->sp_task_begin); pool_free(m->sp_c_of_wave);
     m->sp_tasks = nullptr; m->sp_task_begin = nullptr; m->sp_c_of_wave = nullptr; m->sp_n_tasks = 0;
     pool_free(m->spmv_chunks); m->spmv_chunks = nullptr; m->spmv_num_chunks = 0; m->spmv_plan_long = 0; m->spmv_full_tiles = 0;

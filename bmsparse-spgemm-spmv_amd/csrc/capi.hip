@@ -582,6 +582,15 @@ int bmsp_selftest_mfma_layout(int *mismatches)
     BMSP_API_END
 }
 
+int bmsp_selftest_mfma_f32_cancel(int *mismatches, int *exp_floor)
+{
+    BMSP_API_BEGIN
+    need(mismatches, "mismatches");
+    *mismatches = mfma_f32_selftest(nullptr, true);
+    if (exp_floor) *exp_floor = mac_f32_exp_floor(nullptr);
+    BMSP_API_END
+}
+
 int bmsp_selftest_tile_product(int *mismatches)
 {
     BMSP_API_BEGIN

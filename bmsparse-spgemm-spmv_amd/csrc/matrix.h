@@ -6,7 +6,12 @@
 #include "runtime.h"
 #include <vector>
 
+namespace bmsp { uint64_t next_matrix_uid(); }
+
 struct bmsp_matrix_s {
+    // identity of this matrix's STRUCTURE: a fresh number at construction and after bmsp_matrix_invalidate(m, 1).  What one matrix remembers
+    // about another (the row-merge hint below) is keyed by it -- not by a device pointer, which the pool hands out again
+    uint64_t uid = bmsp::next_matrix_uid();
     int num_rows = 0, num_cols = 0;
     int64_t nnz = 0, block_num = 0;
     bmsp_dtype dtype = BMSP_F32;
@@ -47,7 +52,7 @@ struct bmsp_matrix_s {
     void *lane_tiles = nullptr;   // fp32 matrices: tiles in the lane order of the fp32 MFMA block-MAC (256 B per block): built lazily
     // SpGEMM row-merge paths: the right operand (keys pointer, block count) this matrix was last multiplied with and what that product
     // turned out to need (1 strip mode, 2 task-list mode, 3 the pipeline, 4 column windows) -- the next product of the pair goes there directly
-    const void *rm_partner_keys = nullptr;
+    uint64_t rm_partner_uid = 0;
     int64_t rm_partner_blocks = 0;
     int rm_partner_mode = 0;
     int64_t rm_partner_cw_hash = 0;  // column-window passes: candidate pairs per hashed window that worked for the pair (0: the default)
@@ -90,14 +95,16 @@ namespace bmsp {
 // learned itself: views are made per call, and without this every panel product would pay for a pass that does not fit (hub block-rows).
 inline void rm_hint_inherit(bmsp_matrix_s *view, const bmsp_matrix_s *parent)
 {
-    view->rm_partner_keys = parent->rm_partner_keys; view->rm_partner_blocks = parent->rm_partner_blocks; view->rm_partner_mode = parent->rm_partner_mode;
+    view->rm_partner_uid = parent->rm_partner_uid; view->rm_partner_blocks = parent->rm_partner_blocks; view->rm_partner_mode = parent->rm_partner_mode;
+    view->rm_partner_cw_hash = parent->rm_partner_cw_hash;
 }
 inline void rm_hint_merge(bmsp_matrix_s *parent, const bmsp_matrix_s *view)
 {
-    if (!view->rm_partner_keys) return;
-    const bool same = parent->rm_partner_keys == view->rm_partner_keys && parent->rm_partner_blocks == view->rm_partner_blocks;
+    if (!view->rm_partner_uid) return;
+    const bool same = parent->rm_partner_uid == view->rm_partner_uid;
     const int mode = same && parent->rm_partner_mode > view->rm_partner_mode ? parent->rm_partner_mode : view->rm_partner_mode;
-    parent->rm_partner_keys = view->rm_partner_keys; parent->rm_partner_blocks = view->rm_partner_blocks; parent->rm_partner_mode = mode;
+    parent->rm_partner_uid = view->rm_partner_uid; parent->rm_partner_blocks = view->rm_partner_blocks; parent->rm_partner_mode = mode;
+    if (view->rm_partner_cw_hash) parent->rm_partner_cw_hash = view->rm_partner_cw_hash;
 }
 
 inline size_t dtype_size(bmsp_dtype t) { return t == BMSP_F16 ? 2 : (t == BMSP_F32 ? 4 : 8); }
@@ -135,7 +142,8 @@ bool mac_mfma32_b_dense(const bmsp_matrix_s *B);
 int launch_mac_mfma32(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *task_begin, const uint32_t *c_of_wave, bmsp_matrix_s *A,
                       bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);  // returns the variant it launched (BMSP_MAC_*)
 int mfma32_selftest(hipStream_t st);
-int mfma_f32_selftest(hipStream_t st);
+int mfma_f32_selftest(hipStream_t st, bool cancel = false);
+int mac_f32_exp_floor(hipStream_t st);
 bool launch_mac_f32_mfma(const uint64_t *tasks, uint64_t n_tasks, const uint32_t *task_begin, const uint32_t *c_of_wave, bmsp_matrix_s *A,
                          bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);
 bool mac_strip_eligible(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, uint64_t candidates, uint64_t n_tasks, hipStream_t st);

@@ -617,6 +617,9 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     if (B->max_row_blocks > (int64_t)row_cap) return false;
     const uint64_t slots = first_pos ? std::min<uint64_t>(total, rows * (uint64_t)row_cap) : rows * (uint64_t)row_cap;
     if (slots >= (1ull << 31)) return false;
+    // without T_2 every block-row gets row_cap slots whatever it holds: beyond 4 GB of scratch the caller runs T_2 and comes back with
+    // scratch sized by the candidate pairs (50 M banded rows would have asked for 19 GB and failed the product on NOMEM)
+    if (!first_pos && slots * 12 > (4ull << 30)) return false;
     DevBuf<uint32_t> tmp_off(first_pos ? rows + 1 : 1), cnt(rows + 1), surv_row(rows), nnz_row(rows + 1), cand_row(first_pos ? 1 : rows), t_cols(slots);
     DevBuf<uint64_t> row_val0(rows + 1);
     DevBuf<uint64_t> t_bmps(slots);

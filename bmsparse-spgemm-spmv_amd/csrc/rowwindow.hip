@@ -667,7 +667,7 @@ bool rowmerge_windowed(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     WinPlan P{B->col_mass, (uint32_t)((ncols + kWinGran - 1) / kWinGran), ncols, ce ? (uint32_t)std::max(1, atoi(ce)) : kWinCand,
               he ? (uint32_t)std::max(1, atoi(he)) : kWinCandHash};
     // a pair of operands whose hashed windows overflowed once is cut finer from the start the next time
-    const bool same_pair = A->rm_partner_keys == (const void *)B->keys && A->rm_partner_blocks == B->block_num;
+    const bool same_pair = A->rm_partner_uid == B->uid;
     if (same_pair && A->rm_partner_cw_hash && !he) P.cw_hash = (uint32_t)A->rm_partner_cw_hash;
     DevBuf<uint32_t> n_win(rows + 1), unit_first(rows + 1), overflow(1);
     DevBuf<uint64_t> tab_first(rows + 1);
@@ -745,7 +745,7 @@ bool rowmerge_windowed(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
         if (getenv("BMSP_WIN_DEBUG")) fprintf(stderr, "[win] a hashed window overflowed\n");
         if (attempt == 3 || P.cw_hash <= 64u) return false;
         P.cw_hash /= 2;
-        A->rm_partner_keys = B->keys; A->rm_partner_blocks = B->block_num; A->rm_partner_cw_hash = (int64_t)P.cw_hash;
+        A->rm_partner_uid = B->uid; A->rm_partner_blocks = B->block_num; A->rm_partner_cw_hash = (int64_t)P.cw_hash;
     }
     DevBuf<uint32_t> tile_base((size_t)U + 1), task_base((size_t)U + 1);
     DevBuf<uint64_t> val_base((size_t)U + 1);

@@ -1,5 +1,6 @@
 // runtime.hip -- error state, pooled device memory.
 #include "runtime.h"
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -8,6 +9,12 @@
 #include <cstring>
 
 namespace bmsp {
+
+uint64_t next_matrix_uid()
+{
+    static std::atomic<uint64_t> next{1};
+    return next.fetch_add(1);
+}
 
 static thread_local std::string g_last_error;
 

@@ -1074,9 +1074,12 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     {
         const char *rme = getenv("BMSP_SPGEMM_ROWMERGE");
         const bool rm_force = rme && rme[0] != '0', rm_off = rme && rme[0] == '0', rm_no_strip = rme && rme[0] == '2';
-        const bool known = A->rm_partner_keys == (const void *)B->keys && A->rm_partner_blocks == B->block_num;
+        const bool known = A->rm_partner_uid == B->uid;
         const int hint = known ? A->rm_partner_mode : 0;  // 0 unknown, 1 strip mode fits, 2 task-list mode, 3 pipeline
-        auto remember = [&](int m) { A->rm_partner_keys = B->keys; A->rm_partner_blocks = B->block_num; A->rm_partner_mode = m; };
+        auto remember = [&](int m) {
+            if (A->rm_partner_uid != B->uid) A->rm_partner_cw_hash = 0;
+            A->rm_partner_uid = B->uid; A->rm_partner_blocks = B->block_num; A->rm_partner_mode = m;
+        };
         // numeric stages that work from C's structure alone: the K = 32 MFMA strip kernel (tc_version 4, fp16) and its fp32 form (V15's
         // summation order on v_mfma_f32_16x16x4_f32: any tc_version, as fp32 operands always take V15's numerics)
         const bool rm_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || (A->dtype == BMSP_F32 && !getenv("BMSP_MAC_VALU_DENSE") && !getenv("BMSP_MAC_F32MFMA"));
@@ -1117,6 +1120,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         const bool surely_fits = A->max_row_blocks >= 0 && B->max_row_blocks >= 0 &&
                                  (uint64_t)A->max_row_blocks * (uint64_t)B->max_row_blocks <= (uint64_t)mac_strip_row_cap();
         if (((known && hint == 1) || (hint == 0 && surely_fits)) && n_a && strip_allowed && (mode == BMSP_SORT_AUTO || rm_force) && !rm_off &&
+            (uint64_t)A->num_block_rows() * (uint64_t)mac_strip_row_cap() * 12 <= (4ull << 30) &&  // (beyond: T_2 first, scratch sized by the candidate pairs)
             mac_strip_operands_ok(A, B, st)) {
             uint64_t surv = 0;
             strip_tried = true;

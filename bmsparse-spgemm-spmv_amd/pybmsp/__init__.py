@@ -27,7 +27,7 @@ SYMBOLS = [
     "bmsp_event_create", "bmsp_event_record", "bmsp_event_elapsed_ms", "bmsp_event_destroy",
     "bmsp_matrix_from_mtx", "bmsp_matrix_from_coo", "bmsp_matrix_from_coo_device", "bmsp_matrix_from_arrays",
     "bmsp_matrix_save", "bmsp_matrix_load", "bmsp_matrix_free", "bmsp_matrix_prepare", "bmsp_matrix_invalidate", "bmsp_matrix_info", "bmsp_matrix_arrays", "bmsp_matrix_block_row_ptr",
-    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmv_launch_info", "bmsp_spmm", "bmsp_spgemm", "bmsp_spgemm_symbolic", "bmsp_spgemm_numeric", "bmsp_selftest_mfma_layout", "bmsp_selftest_mfma_f32_chain", "bmsp_selftest_tile_product", "bmsp_segsort_u64",
+    "bmsp_matrix_to_coo_host", "bmsp_matrix_to_coo_device", "bmsp_matrix_to_csr_device", "bmsp_matrix_from_csr_device", "bmsp_matrix_compare", "bmsp_matrix_compare_device", "bmsp_spmv", "bmsp_spmv_launch_info", "bmsp_spmm", "bmsp_spgemm", "bmsp_spgemm_symbolic", "bmsp_spgemm_numeric", "bmsp_selftest_mfma_layout", "bmsp_selftest_mfma_f32_chain", "bmsp_selftest_tile_product", "bmsp_selftest_mfma_f32_cancel", "bmsp_segsort_u64",
     "bmsp_partition_rows", "bmsp_matrix_row_panel", "bmsp_matrix_concat_panels",
     "bmsp_comm_unique_id", "bmsp_comm_init", "bmsp_comm_init_from_env", "bmsp_comm_init_loopback", "bmsp_shard_layout", "bmsp_shard_row_slices", "bmsp_comm_info", "bmsp_comm_free", "bmsp_spgemm_sharded", "bmsp_spgemm_sharded_ex", "bmsp_spmv_sharded",
     "bmsp_csr_from_mtx", "bmsp_csr_from_arrays", "bmsp_csr_info", "bmsp_csr_arrays", "bmsp_csr_multiply",
@@ -116,6 +116,7 @@ def lib():
         L.bmsp_selftest_mfma_layout.argtypes = [p(i)]
         L.bmsp_selftest_mfma_f32_chain.argtypes = [p(i)]
         L.bmsp_selftest_tile_product.argtypes = [p(i)]
+        L.bmsp_selftest_mfma_f32_cancel.argtypes = [p(i), p(i)]
         L.bmsp_segsort_u64.argtypes = [vp, vp, i, i64, vp, i64, vp]
         L.bmsp_partition_rows.argtypes = [vp, vp, i, vp]
         L.bmsp_matrix_row_panel.argtypes = [vp, i64, i64, p(vp)]

@@ -256,6 +256,12 @@ int bmsp_selftest_mfma_layout(int *mismatches);
  * block-MAC on the matrix cores with values bit-identical to the vector-ALU kernel (BMSP_MAC_F32MFMA=1 selects that kernel; it is not the
  * default: measured on MI355X it is bound by the 256-byte operand tiles it reads and no faster than the vector-ALU kernels). */
 int bmsp_selftest_mfma_f32_chain(int *mismatches);
+/* The same on the corner the exponent guard of the fp32 matrix-core kernels must know about: every product a normal number (~2^-123), signs
+ * alternating, so that the partial sums cancel into the subnormal range.  *mismatches = result elements that differ from the host's fmaf
+ * chain; *exp_floor (may be NULL) = the smallest sum of the two operands' smallest biased exponents those kernels then accept: 128 when
+ * the instruction is the chain there too, 174 otherwise (products can then not cancel below 2^-126) -- below the floor V15's vector-ALU
+ * kernel computes the product. */
+int bmsp_selftest_mfma_f32_cancel(int *mismatches, int *exp_floor);
 /* Hardware self test of the byte-permute form of bmp_calculator (src/bmSparse_SPGEMM.cu:787-810) the row-merge passes use: 2^20 pairs of
  * bitmaps of every density, the v_perm_b32 sign-replication product on the row-major copy of B's tile against the multiply form on the
  * tile as stored.  *mismatches = pairs whose products differ (0 on gfx950). */

@@ -452,6 +452,25 @@ def test_mfma_16x16x32_lane_layout(bmsp):
     assert bad.value == 0
 
 
+def test_fp32_mfma_cancellation_corner(oracle, bmsp):
+    """the fp32 matrix-core kernels are V15's fmaf chain while every product is a normal number -- but normal products of
+    alternating sign can still CANCEL into subnormal sums.  The hardware self test runs exactly that (products ~2^-123, sums ~2^-140 and
+    below, subnormal starting values); the library derives its exponent floor from the outcome (128, or 174 where the pipe differs), and a
+    product built to cancel that way must equal the oracle bit for bit whichever kernel the floor sends it to."""
+    import ctypes
+    from pybmsp import gen
+    bad, floor = ctypes.c_int(-1), ctypes.c_int(-1)
+    bmsp.check(bmsp.lib().bmsp_selftest_mfma_f32_cancel(ctypes.byref(bad), ctypes.byref(floor)))
+    assert bad.value >= 0 and floor.value == (128 if bad.value == 0 else 174), (bad.value, floor.value)
+    n, _, r, c, v = gen.fem_like(10, "27pt")
+    sign = np.where((r + c) % 2 == 0, 1.0, -1.0)
+    va = (sign * (1.0 + (np.arange(r.size) % 7) * 2.0 ** -21) * 2.0 ** -60).astype(np.float32).astype(np.float64)
+    vb = ((1.0 + (np.arange(r.size) % 5) * 2.0 ** -22) * 2.0 ** -63).astype(np.float32).astype(np.float64)
+    st = check_spgemm(oracle, bmsp, (n, n, r, c, va), (n, n, r, c, vb), 0, 0, 5, exact_expected=True)
+    assert st["sort_path"] == 2, st
+    assert (st["mac_variant"] == 3) == (floor.value == 128), (st, floor.value)   # exponents sum to ~2 * 127 - 123 = 131: above 128, below 174
+
+
 def test_tile_product_byte_permute_form(bmsp):
     """the v_perm_b32 form of the 8x8 boolean tile product (bmp_calculator) used by the column-window passes, against the multiply form,
     on the hardware: the selector semantics (8..11 = sign of the odd bytes) are an ISA detail worth pinning."""
