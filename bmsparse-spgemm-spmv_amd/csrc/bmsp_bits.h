@@ -109,6 +109,30 @@ BMSP_HD uint64_t tile_product_rm(uint64_t a, uint64_t br)
     return ((uint64_t)ch << 32) | (uint64_t)cl;
 }
 
+#if defined(__HIPCC__)
+// bmp_calculator for one lane's B tile (row-major bitmap, halves bh : bl) against an A tile that is the same for the whole wave: ah : al
+// its bitmap, cols = tile_or_bytes(a) (bit 7-k: column k in use), all three in scalar registers.  C = OR over the columns k the A tile
+// uses of (rows i with A(i,k)) x (row k of B): the masks are scalar arithmetic, a lane spends one v_perm_b32 and two v_and_or_b32 per k.
+__device__ __forceinline__ uint64_t tile_product_scalar_a(uint32_t ah, uint32_t al, uint32_t cols, uint32_t bh, uint32_t bl)
+{
+    uint32_t ch = 0, cl = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if ((cols >> (7 - k)) & 1u) {  // (wave-uniform)
+            const uint32_t mh = ((ah >> (7 - k)) & 0x01010101u) * 0xffu, ml = ((al >> (7 - k)) & 0x01010101u) * 0xffu;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t rk = __builtin_amdgcn_perm(0u, k < 4 ? bh : bl, 0x01010101u * (uint32_t)(3 - (k & 3)));
+#else
+            const uint32_t rk = (((k < 4 ? bh : bl) >> (8 * (3 - (k & 3)))) & 0xffu) * 0x01010101u;  // (the host pass of the compiler only needs it to parse)
+#endif
+            ch |= mh & rk;
+            cl |= ml & rk;
+        }
+    }
+    return ((uint64_t)ch << 32) | (uint64_t)cl;
+}
+#endif
+
 // double -> IEEE binary16 bits, round to nearest even in one step (what `(half)double` does in the
 // reference, src/bmSpMatrix.cu:141; include/half.hpp:373-374).
 BMSP_HD uint16_t f64_to_f16_bits(double x)

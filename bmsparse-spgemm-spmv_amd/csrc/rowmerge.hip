@@ -28,6 +28,7 @@ struct RowMergeArgs {
     const uint64_t *a_keys, *a_bmps;
     const uint32_t *a_rowptr;
     const uint64_t *b_keys, *b_bmps;
+    const uint32_t *b_recs;
     const uint32_t *b_rowptr;
     uint32_t block_rows, b_block_rows;
     uint32_t row_cap;         // distinct C tiles per block-row the caller accepts (<= kRowCap)
@@ -56,14 +57,15 @@ struct alignas(16) RowLds {
 
 struct WalkArgs {
     const uint64_t *a_keys, *a_bmps;
-    const uint64_t *b_keys, *b_bmps;
+    const uint32_t *b_recs;  // per B tile {bitmap ROW-major (lo, hi), block column, rows the tile uses} (matrix.h: sym_recs): one 16-byte load per candidate pair
     const uint32_t *b_rowptr;
     uint32_t b_block_rows;
 };
+typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
 
 // Walks the candidate pairs of the A tiles [a0, a1) (one block-row of A).  64 / LPT A tiles at a time, LPT lanes each: the lanes of a
 // group walk B's block-row k of their tile LPT tiles per step (the words of the next step are requested before the current ones are
-// used).  step(live, a, t, j, abm, bbm) is called by the whole wave once per step -- live: this lane holds a candidate (A tile a, B
+// used).  step(live, a, t, j, abm, rows, bbm) is called by the whole wave once per step -- live: this lane holds a candidate (A tile a, B
 // tile t of block column j, their bitmaps) -- and returns false (wave-uniformly) to stop the walk.  LPT = 64: one A tile at a time, i.e.
 // the candidates arrive in ascending A tile.
 template <int LPT = 16, int DEPTH = 4, typename Step>
@@ -71,9 +73,14 @@ __device__ __forceinline__ bool walk_row(const WalkArgs &g, ChunkLds &L, uint32_
 {
     constexpr uint32_t GROUPS = 64 / LPT;
     struct Cur {
-        uint32_t u, t, end, j;
-        uint64_t abm, bbm;
+        uint32_t u, t, end, j, rows;  // rows: bit 7-k = row k of the B tile holds a value
+        uint64_t abm, bbm;            // bbm: the B tile ROW-major
         bool valid;  // (wave-uniform) false: past the chunk's last step
+    };
+    const u32x4r *const recs = (const u32x4r *)g.b_recs;
+    auto load = [&](uint32_t t, uint32_t &j, uint32_t &rows, uint64_t &bm) {
+        const u32x4r r = recs[t];
+        j = r[2]; rows = r[3]; bm = ((uint64_t)r[1] << 32) | (uint64_t)r[0];
     };
     for (uint32_t base = a0; base < a1; base += 64) {
         const uint32_t a = base + (uint32_t)lane;
@@ -94,8 +101,8 @@ __device__ __forceinline__ bool walk_row(const WalkArgs &g, ChunkLds &L, uint32_
             c.end = c.u < na ? L.aend[c.u] : 0u;
             c.abm = L.abmp[min(c.u, 63u)];
             c.t = (c.u < na ? L.abeg[c.u] : 0u) + (uint32_t)lane % (uint32_t)LPT;
-            c.j = 0; c.bbm = 0;
-            if (c.t < c.end) { c.j = key_col(g.b_keys[c.t]); c.bbm = g.b_bmps[c.t]; }
+            c.j = 0; c.bbm = 0; c.rows = 0;
+            if (c.t < c.end) load(c.t, c.j, c.rows, c.bbm);
             return c;
         };
         // the step after c: the group's next LPT tiles, or the first step of the next group
@@ -104,8 +111,8 @@ __device__ __forceinline__ bool walk_row(const WalkArgs &g, ChunkLds &L, uint32_
             if (!c.valid) return n;
             if (__any(c.t + (uint32_t)LPT < c.end)) {
                 n.t = c.t + (uint32_t)LPT;
-                n.j = 0; n.bbm = 0;
-                if (n.t < n.end) { n.j = key_col(g.b_keys[n.t]); n.bbm = g.b_bmps[n.t]; }
+                n.j = 0; n.bbm = 0; n.rows = 0;
+                if (n.t < n.end) load(n.t, n.j, n.rows, n.bbm);
             } else {
                 g4 += GROUPS;
                 if (g4 < na) n = enter();
@@ -122,18 +129,18 @@ __device__ __forceinline__ bool walk_row(const WalkArgs &g, ChunkLds &L, uint32_
                 Cur c = enter();
                 while (__any(c.t < c.end)) {
                     const uint32_t tn = c.t + (uint32_t)LPT;
-                    uint32_t jn = 0;
+                    uint32_t jn = 0, rn = 0;
                     uint64_t bn = 0;
-                    if (tn < c.end) { jn = key_col(g.b_keys[tn]); bn = g.b_bmps[tn]; }
-                    if (!step(c.t < c.end, base + c.u, c.t, c.j, c.abm, c.bbm)) return false;
-                    c.t = tn; c.j = jn; c.bbm = bn;
+                    if (tn < c.end) load(tn, jn, rn, bn);
+                    if (!step(c.t < c.end, base + c.u, c.t, c.j, c.abm, c.rows, c.bbm)) return false;
+                    c.t = tn; c.j = jn; c.rows = rn; c.bbm = bn;
                 }
             }
         } else if constexpr (DEPTH == 4) {
             Cur q0 = enter(), q1 = after(q0), q2 = after(q1), q3 = after(q2);
             while (q0.valid) {
                 if (__any(q0.t < q0.end)) {
-                    if (!step(q0.t < q0.end, base + q0.u, q0.t, q0.j, q0.abm, q0.bbm)) return false;
+                    if (!step(q0.t < q0.end, base + q0.u, q0.t, q0.j, q0.abm, q0.rows, q0.bbm)) return false;
                 }
                 q0 = q1; q1 = q2; q2 = q3; q3 = after(q3);
             }
@@ -141,7 +148,7 @@ __device__ __forceinline__ bool walk_row(const WalkArgs &g, ChunkLds &L, uint32_
             Cur q0 = enter(), q1 = after(q0);
             while (q0.valid) {
                 if (__any(q0.t < q0.end)) {
-                    if (!step(q0.t < q0.end, base + q0.u, q0.t, q0.j, q0.abm, q0.bbm)) return false;
+                    if (!step(q0.t < q0.end, base + q0.u, q0.t, q0.j, q0.abm, q0.rows, q0.bbm)) return false;
                 }
                 q0 = q1; q1 = after(q1);
             }
@@ -198,15 +205,16 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
     for (uint32_t s = (uint32_t)lane; s < (uint32_t)kHash; s += 64) { S.hk[s] = kEmpty; S.hb[s] = 0ull; }
     uint32_t n = 0;       // distinct columns so far (wave-uniform)
     uint32_t surv = 0;    // this lane's surviving pairs
-    const WalkArgs wa{g.a_keys, g.a_bmps, g.b_keys, g.b_bmps, g.b_rowptr, g.b_block_rows};
-    const bool done = walk_row<16, DEPTH>(wa, S.ch, a0, a1, lane, [&](bool live, uint32_t, uint32_t, uint32_t j, uint64_t abm, uint64_t bbm) {
+    const WalkArgs wa{g.a_keys, g.a_bmps, g.b_recs, g.b_rowptr, g.b_block_rows};
+    const bool done = walk_row<16, DEPTH>(wa, S.ch, a0, a1, lane, [&](bool live, uint32_t, uint32_t, uint32_t j, uint64_t abm, uint32_t rows, uint64_t bbm) {
         if (n > g.row_cap) return false;
-        const bool keep = live && !tile_product_empty(abm, bbm);  // multiplication_checker (:742-757)
+        const bool keep = live && (tile_or_bytes(abm) & rows);  // multiplication_checker (:742-757): a column of the A tile meets a row of the B tile
         surv += keep ? 1u : 0u;
         bool fresh = false;
         if (keep) {
-            // bmp_calculator (:787-810); two full tiles: a full one
-            const uint64_t prod = (abm & bbm) == ~0ull ? ~0ull : tile_product_bmp(abm, bbm);
+            // bmp_calculator (:787-810) in its byte-permute form on the row-major B tile (88 instead of ~240 vector instructions: this pass was
+            // 85 % VALU-bound on the FEM-like product); two full tiles: a full one
+            const uint64_t prod = (abm & bbm) == ~0ull ? ~0ull : tile_product_rm(abm, bbm);
             const uint32_t slot = hash_insert(S.hk, j, fresh);
             atomicOr((unsigned long long *)&S.hb[slot], (unsigned long long)prod);
         }
@@ -333,9 +341,13 @@ __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g
     bool done = a1 - a0 <= 65535u;
     // (one A tile at a time: the columns of one block-row of B are distinct, so the count a pair finds at its C tile is the number of that
     // tile's tasks from smaller A tiles -- its place inside the tile, in V15's summation order (:269-273))
-    if (done) done = walk_row<64, DEPTH>(g.w, S.ch, a0, a1, lane, [&](bool live, uint32_t a, uint32_t t, uint32_t j, uint64_t abm, uint64_t bbm) {
+    if (done) done = walk_row<64, DEPTH>(g.w, S.ch, a0, a1, lane, [&](bool live, uint32_t a, uint32_t t, uint32_t j, uint64_t abm, uint32_t rows, uint64_t bbm) {
         if (n > kTlCap || ns + 64u > 65535u) return false;  // (task offsets inside a block-row are kept in 16 bits)
-        const bool keep = live && !tile_product_empty(abm, bbm);  // multiplication_checker (:742-757)
+        // one A tile per step: its bitmap, the columns it uses and the product's byte masks are wave-uniform -- scalar registers, scalar ALU
+        // (the pass spent 8.3 vector instructions per candidate pair, 70 % of the vector ALU, most of them in the 8 x 8 boolean product)
+        const uint32_t ah = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(abm >> 32)), al = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)abm);
+        const uint32_t cols = tile_or_bytes(((uint64_t)ah << 32) | (uint64_t)al);
+        const bool keep = live && (cols & rows);  // multiplication_checker (:742-757)
         const uint64_t bal = __ballot(keep);
         bool fresh = false;
         if (keep) {
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g
             const uint32_t old = atomicAdd(&S.tc[slot >> 1], 1u << (16u * (slot & 1u)));
             const uint32_t k = ns + (uint32_t)__popcll(bal & lanemask_lt());
             g.s_surv[off + k] = ((uint64_t)slot << 48) | ((uint64_t)(a - a0) << 32) | (uint64_t)t;
-            g.s_prod[off + k] = (abm & bbm) == ~0ull ? ~0ull : tile_product_bmp(abm, bbm);  // bmp_calculator (:787-810); two full tiles: a full one
+            g.s_prod[off + k] = tile_product_scalar_a(ah, al, cols, (uint32_t)(bbm >> 32), (uint32_t)bbm);  // bmp_calculator (:787-810)
             g.s_ord[off + k] = (uint16_t)((old >> (16u * (slot & 1u))) & 0xffffu);
         }
         ns += (uint32_t)__popcll(bal);
@@ -613,6 +625,7 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     if (first_pos && (total == 0 || total >= (1ull << 32))) return false;
     ensure_rowptr(A, st);
     ensure_row_stats(B, st);
+    ensure_sym_recs(B, st);
     // (a block-row of C holds at least the tiles of the longest block-row of B it meets: operands with a hub block-row are not tried)
     if (B->max_row_blocks > (int64_t)row_cap) return false;
     const uint64_t slots = first_pos ? std::min<uint64_t>(total, rows * (uint64_t)row_cap) : rows * (uint64_t)row_cap;
@@ -628,7 +641,7 @@ bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     if (first_pos) device_exclusive_scan<uint32_t>(RowSlotsIn{first_pos, A->rowptr, rows, row_cap}, PtrOut<uint32_t>{tmp_off.p}, rows + 1, st);
     RowMergeArgs g{};
     g.a_keys = A->keys; g.a_bmps = A->bmps; g.a_rowptr = A->rowptr;
-    g.b_keys = B->keys; g.b_bmps = B->bmps; g.b_rowptr = B->rowptr;
+    g.b_keys = B->keys; g.b_bmps = B->bmps; g.b_recs = B->sym_recs; g.b_rowptr = B->rowptr;
     g.block_rows = (uint32_t)rows; g.b_block_rows = (uint32_t)B->num_block_rows(); g.row_cap = row_cap;
     g.tmp_off = first_pos ? tmp_off.p : nullptr; g.cand = first_pos ? nullptr : cand_row.p; g.t_cols = t_cols.p; g.t_bmps = t_bmps.p; g.cnt = cnt.p;
     g.surv = surv_row.p; g.nnz = nnz_row.p; g.overflow = (uint32_t *)(acc.p + 2);
@@ -706,6 +719,7 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     if (total * 42 > (16ull << 30)) return false;  // scratch: 42 bytes per candidate pair
     ensure_rowptr(A, st);
     ensure_row_stats(B, st);
+    ensure_sym_recs(B, st);
     // (a block-row of C holds at least the tiles of the longest block-row of B it meets: operands with a hub block-row -- power-law graphs --
     // go to the pipeline without a pass being tried, and without its scratch being allocated)
     if (B->max_row_blocks > (int64_t)(kTlCap + 63)) return false;
@@ -716,7 +730,7 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     DevBuf<unsigned long long> acc(3);  // [1] most C tiles in a block-row, [2] overflow flag
     BMSP_HIP(hipMemsetAsync(acc.p, 0, 24, st));
     TaskListArgs g{};
-    g.w = WalkArgs{A->keys, A->bmps, B->keys, B->bmps, B->rowptr, (uint32_t)B->num_block_rows()};
+    g.w = WalkArgs{A->keys, A->bmps, B->sym_recs, B->rowptr, (uint32_t)B->num_block_rows()};
     g.a_rowptr = A->rowptr; g.first_pos = first_pos; g.block_rows = (uint32_t)rows;
     g.cnt = cnt.p; g.surv = surv_row.p; g.nnz = nnz_row.p; g.overflow = (uint32_t *)(acc.p + 2);
     g.s_surv = s_surv.p; g.s_prod = s_prod.p; g.s_ord = s_ord.p; g.s_tasks = s_tasks.p; g.s_cols = s_cols.p; g.s_begin = s_begin.p;

@@ -280,40 +280,22 @@ __device__ __forceinline__ RoundRegs round_regs(const RoundLoad &r)
 // tile: every lane then ran the whole 8x8 boolean product -- 130 vector instructions per step, 411 M per product on R-MAT 2^16.)
 struct StepScalars {
     uint32_t v, s0, len, x0, ah, al, cols;  // A tile of the round, its stretch, first pair of the step, its bitmap, its columns in use
-    bool ok;
 };
+// (no branch on "is there a step i": everything below is scalar code on values read with v_readlane, and a branch would make the compiler
+// keep the results in vector registers -- measured: 157 vector instructions per step, the product's masks built with quarter-rate
+// v_mul_lo_u32.  Beyond the round's last step the ballot names the last A tile and x0 lies past its stretch: no lane is live.)
 __device__ __forceinline__ StepScalars step_scalars(const RoundRegs &q, uint32_t i)
 {
-    StepScalars t{};
-    t.ok = i < q.S;
-    if (t.ok) {
-        // last A tile whose first step is <= i (tiles without a step share their start with the next tile: the last of a run owns it)
-        t.v = (uint32_t)__popcll(__ballot(q.P <= i)) - 1u;
-        t.s0 = (uint32_t)__builtin_amdgcn_readlane((int)q.seg, (int)t.v);
-        t.len = (uint32_t)__builtin_amdgcn_readlane((int)q.len, (int)t.v);
-        t.x0 = (i - (uint32_t)__builtin_amdgcn_readlane((int)q.P, (int)t.v)) << 6;
-        t.ah = (uint32_t)__builtin_amdgcn_readlane((int)q.ahi, (int)t.v);
-        t.al = (uint32_t)__builtin_amdgcn_readlane((int)q.alo, (int)t.v);
-        t.cols = tile_or_bytes(((uint64_t)t.ah << 32) | (uint64_t)t.al);  // bit 7-k: column k of the A tile holds a value
-    }
+    StepScalars t;
+    // last A tile whose first step is <= i (tiles without a step share their start with the next tile: the last of a run owns it)
+    t.v = (uint32_t)__popcll(__ballot(q.P <= i)) - 1u;
+    t.s0 = (uint32_t)__builtin_amdgcn_readlane((int)q.seg, (int)t.v);
+    t.len = (uint32_t)__builtin_amdgcn_readlane((int)q.len, (int)t.v);
+    t.x0 = (i - (uint32_t)__builtin_amdgcn_readlane((int)q.P, (int)t.v)) << 6;
+    t.ah = (uint32_t)__builtin_amdgcn_readlane((int)q.ahi, (int)t.v);
+    t.al = (uint32_t)__builtin_amdgcn_readlane((int)q.alo, (int)t.v);
+    t.cols = tile_or_bytes(((uint64_t)t.ah << 32) | (uint64_t)t.al);  // bit 7-k: column k of the A tile holds a value
     return t;
-}
-
-// bmp_calculator (:787-810) for one lane's B tile (row-major bitmap br) against the wave's A tile: C = OR_k (rows i with A(i,k)) x (row k
-// of B), over the columns k the A tile uses; the A side is scalar
-__device__ __forceinline__ uint64_t tile_product_scalar_a(const StepScalars &t, uint32_t bh, uint32_t bl)
-{
-    uint32_t ch = 0, cl = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if ((t.cols >> (7 - k)) & 1u) {  // (wave-uniform)
-            const uint32_t mh = ((t.ah >> (7 - k)) & 0x01010101u) * 0xffu, ml = ((t.al >> (7 - k)) & 0x01010101u) * 0xffu;
-            const uint32_t rk = __builtin_amdgcn_perm(0u, k < 4 ? bh : bl, 0x01010101u * (uint32_t)(3 - (k & 3)));
-            ch |= mh & rk;
-            cl |= ml & rk;
-        }
-    }
-    return ((uint64_t)ch << 32) | (uint64_t)cl;
 }
 
 // exclusive scan of one value per thread across the kWinThreads-thread workgroup (lds: kWinWaves words; two barriers inside)
@@ -394,7 +376,7 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_count_kernel(WinArgs g)
             for (int b = 0; b < kWinBatchCount; b++) {
                 t[b] = step_scalars(q, i0 + (uint32_t)(kWinWaves * b));
                 r[b] = u32x4w{0u, 0u, 0u, 0u};
-                if (t[b].ok && t[b].x0 + (uint32_t)lane < t[b].len) r[b] = recs[t[b].s0 + t[b].x0 + (uint32_t)lane];
+                if (t[b].x0 + (uint32_t)lane < t[b].len) r[b] = recs[t[b].s0 + t[b].x0 + (uint32_t)lane];
             }
 #pragma unroll
             for (int b = 0; b < kWinBatchCount; b++) {
@@ -403,12 +385,12 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_count_kernel(WinArgs g)
                     if (over) break;
                 }
                 // multiplication_checker (:742-757): a column of the A tile meets a row of the B tile (no record beyond the stretch: rows in use = 0)
-                const bool keep = t[b].ok && (t[b].cols & r[b][3]);
+                const bool keep = (t[b].cols & r[b][3]) != 0u;
                 bool fresh = false;
                 if (keep) {
                     const uint32_t slot = slot_insert<HASH, T>(keys, r[b][2], u.lo, fresh);
                     atomicAdd(&cnt[slot], 1u);
-                    atomicOr((unsigned long long *)&bmp[slot], (unsigned long long)tile_product_scalar_a(t[b], r[b][1], r[b][0]));
+                    atomicOr((unsigned long long *)&bmp[slot], (unsigned long long)tile_product_scalar_a(t[b].ah, t[b].al, t[b].cols, r[b][1], r[b][0]));
                 }
                 if (HASH) {
                     const uint32_t nf = (uint32_t)__popcll(__ballot(fresh));
@@ -493,7 +475,7 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g)
     const uint64_t vb = g.val_base[unit];
     for (int s = threadIdx.x; s < T; s += kWinThreads) {
         hit2[0][s] = 0ull;
-        if (!HASH) hit2[1][s] = 0ull;
+        if constexpr (!HASH) hit2[1][s] = 0ull;
         if (HASH) keys[s] = kHashEmpty;
     }
     if (HASH) __syncthreads();
@@ -545,11 +527,11 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g)
         for (int b = 0; b < kWinBatch; b++) {
             t0[b] = step_scalars(q, (uint32_t)w + (uint32_t)(kWinWaves * b));
             f[b] = u32x2w{0u, 0u};
-            if (t0[b].ok && t0[b].x0 + (uint32_t)lane < t0[b].len) f[b] = recs[2u * (t0[b].s0 + t0[b].x0 + (uint32_t)lane) + 1u];
+            if (t0[b].x0 + (uint32_t)lane < t0[b].len) f[b] = recs[2u * (t0[b].s0 + t0[b].x0 + (uint32_t)lane) + 1u];
         }
         // the previous round's marks become task slots taken, while this round's first records travel
         if (r0 != u.a0) {
-            uint64_t *const prev = hit2[HASH ? 0 : (par ^ 1u)];
+            uint64_t *const prev = hit2[HASH ? 0u : (par ^ 1u)];
             for (int s = threadIdx.x; s < T; s += kWinThreads) {
                 const uint64_t h = prev[s];
                 if (h) { begin[s] += (uint32_t)__popcll(h); prev[s] = 0ull; }
@@ -559,7 +541,7 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g)
         // first half: the round's A tiles mark the columns they reach
 #pragma unroll
         for (int b = 0; b < kWinBatch; b++)
-            if (t0[b].ok && (t0[b].cols & f[b][1])) atomicOr((unsigned long long *)&hit[slot_find<HASH, T>(keys, f[b][0], u.lo)], 1ull << t0[b].v);
+            if (t0[b].cols & f[b][1]) atomicOr((unsigned long long *)&hit[slot_find<HASH, T>(keys, f[b][0], u.lo)], 1ull << t0[b].v);
         for (uint32_t i0 = (uint32_t)w + (uint32_t)(kWinWaves * kWinBatch); i0 < q.S; i0 += (uint32_t)(kWinWaves * kWinBatch)) {
             StepScalars t[kWinBatch];
             u32x2w r[kWinBatch];
@@ -567,16 +549,16 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g)
             for (int b = 0; b < kWinBatch; b++) {
                 t[b] = step_scalars(q, i0 + (uint32_t)(kWinWaves * b));
                 r[b] = u32x2w{0u, 0u};
-                if (t[b].ok && t[b].x0 + (uint32_t)lane < t[b].len) r[b] = recs[2u * (t[b].s0 + t[b].x0 + (uint32_t)lane) + 1u];
+                if (t[b].x0 + (uint32_t)lane < t[b].len) r[b] = recs[2u * (t[b].s0 + t[b].x0 + (uint32_t)lane) + 1u];
             }
 #pragma unroll
             for (int b = 0; b < kWinBatch; b++)
-                if (t[b].ok && (t[b].cols & r[b][1])) atomicOr((unsigned long long *)&hit[slot_find<HASH, T>(keys, r[b][0], u.lo)], 1ull << t[b].v);
+                if (t[b].cols & r[b][1]) atomicOr((unsigned long long *)&hit[slot_find<HASH, T>(keys, r[b][0], u.lo)], 1ull << t[b].v);
         }
         __syncthreads();
         // second half: a pair's place inside its C tile = tasks of earlier rounds + marks of smaller A tiles of this round
         auto place = [&](const StepScalars &t, const u32x2w &r) {
-            if (t.ok && (t.cols & r[1])) {
+            if (t.cols & r[1]) {
                 const uint32_t slot = slot_find<HASH, T>(keys, r[0], u.lo);
                 g.tasks[kb + begin[slot] + (uint32_t)__popcll(hit[slot] & ((1ull << t.v) - 1ull))] =
                     ((uint64_t)(r0 + t.v) << 32) | (uint64_t)(t.s0 + t.x0 + (uint32_t)lane);
@@ -591,7 +573,7 @@ __global__ __launch_bounds__(kWinThreads) void rowwin_fill_kernel(WinArgs g)
             for (int b = 0; b < kWinBatch; b++) {
                 t[b] = step_scalars(q, i0 + (uint32_t)(kWinWaves * b));
                 r[b] = u32x2w{0u, 0u};
-                if (t[b].ok && t[b].x0 + (uint32_t)lane < t[b].len) r[b] = recs[2u * (t[b].s0 + t[b].x0 + (uint32_t)lane) + 1u];
+                if (t[b].x0 + (uint32_t)lane < t[b].len) r[b] = recs[2u * (t[b].s0 + t[b].x0 + (uint32_t)lane) + 1u];
             }
 #pragma unroll
             for (int b = 0; b < kWinBatch; b++) place(t[b], r[b]);
