@@ -641,7 +641,8 @@ def bench_spgemm(B, gen, np, args):
                     "gflops_with_prepare": round(2.0 * P / (t_total + prepare_ms * 1e-3) / 1e9, 2),
                     "stage_us": {k: round(best["t_us"][i], 1) for k, i in stage_idx},
                     "stage_GBs": stage_gbs, "stage_frac_of_hbm_peak": stage_frac,
-                    "sort_path": {0: "global radix", 1: "segmented", 2: "none (row-merge: C's structure formed per block-row in LDS)",
+                    "sort_path": {0: "global radix", 1: "segmented" + {0: "", 1: " (long block-rows: pieces + merge passes)",
+                                                                       2: " (long block-rows: counting passes on the column bits)"}[best.get("sort_long", 0)], 2: "none (row-merge: C's structure formed per block-row in LDS)",
                                   3: "none (column windows: C's structure formed per block-row and window of block columns in dense LDS tables)"}[best["sort_path"]],
                     "roofline": roof})
         del A, At

@@ -301,7 +301,7 @@ void add_stats(bmsp_spgemm_stats &ps, const bmsp_spgemm_stats &one)
     ps.task_list_size += one.task_list_size; ps.bmp_reduction += one.bmp_reduction; ps.surviving_tasks += one.surviving_tasks;
     ps.c_blocks += one.c_blocks; ps.c_nnz += one.c_nnz;
     for (int i = 0; i < 10; i++) ps.t_us[i] += one.t_us[i];
-    ps.sort_path = one.sort_path; ps.mac_kernel = one.mac_kernel; ps.mac_variant = one.mac_variant;
+    ps.sort_path = one.sort_path; ps.mac_kernel = one.mac_kernel; ps.mac_variant = one.mac_variant; ps.sort_long = std::max(ps.sort_long, one.sort_long);
 }
 }  // namespace
 

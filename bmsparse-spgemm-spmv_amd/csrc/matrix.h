@@ -180,7 +180,7 @@ struct PingPong;
 // stable sort of (key, task) pairs inside the runs of equal (key >> jbits): the SpGEMM's segmented path
 // false = some block-row has more tasks than the LDS paths hold; nothing was modified and the caller sorts globally
 bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st, uint64_t max_seg_bound = 0,
-                             uint64_t seg_count_bound = 0);
+                             uint64_t seg_count_bound = 0, int *long_mode = nullptr);  // *long_mode: BMSP_SORT_LONG_* (0: no long segment)
 void segsort_check_violation();
 void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const int *d_segs, int64_t num_segs,
                  hipStream_t st);

@@ -142,6 +142,7 @@ struct SegClassify {
         const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
         return hi > lo ? (uint32_t)(hi - lo) : 0u;
     }
+    __device__ bool is_long(uint32_t l) const { return l > wave_max && l > kBlockSegMax; }
     // packed counts: [0,21) wave-class segments, [21,42) block-class, [42,63) long
     __device__ uint64_t operator()(uint64_t s) const
     {
@@ -346,8 +347,8 @@ void segsort_u64(uint64_t *d_keys, void *d_vals, int val_bytes, int64_t n, const
 constexpr uint32_t kTaskWaveMax = 2048, kTaskBlockIdxBits = 12;
 
 template <typename W, int THREADS, bool BLOCK_SYNC, uint32_t IDX_BITS>
-__device__ __forceinline__ void sort_task_segment(W *a, uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, uint64_t lo, uint32_t len, uint32_t p_min,
-                                                  uint64_t col_mask, uint32_t tid)
+__device__ __forceinline__ void sort_task_segment(W *a, const uint64_t *keys, uint64_t *keys_out, uint32_t *__restrict__ perm, uint64_t lo, uint32_t len,
+                                                  uint32_t p_min, uint64_t col_mask, uint32_t tid)
 {
     uint32_t P = p_min;
     while (P < len) P <<= 1;
@@ -358,7 +359,7 @@ __device__ __forceinline__ void sort_task_segment(W *a, uint64_t *__restrict__ k
     bitonic_words<W, THREADS, BLOCK_SYNC>(a, P, tid);
     for (uint32_t e = tid; e < len; e += THREADS) {
         const W c = a[e];
-        keys[lo + e] = row_part | (uint64_t)(c >> IDX_BITS);
+        keys_out[lo + e] = row_part | (uint64_t)(c >> IDX_BITS);
         perm[lo + e] = (uint32_t)(lo + (uint32_t)(c & (W)((1u << IDX_BITS) - 1u)));
     }
 }
@@ -435,8 +436,8 @@ struct BitonicPhase {
 };
 
 template <typename W, int E, uint32_t IDX_BITS>
-__device__ __forceinline__ void sort_task_segment_regs(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, uint64_t lo, uint32_t len, uint64_t col_mask,
-                                                       int lane)
+__device__ __forceinline__ void sort_task_segment_regs(const uint64_t *keys, uint64_t *keys_out, uint32_t *__restrict__ perm, uint64_t lo, uint32_t len,
+                                                       uint64_t col_mask, int lane)
 {
     W x[E];
     const uint64_t row_part = keys[lo] & ~col_mask;  // constant inside a segment
@@ -450,7 +451,7 @@ __device__ __forceinline__ void sort_task_segment_regs(uint64_t *__restrict__ ke
     for (int e = 0; e < E; e++) {
         const uint32_t i = (uint32_t)lane * E + (uint32_t)e;
         if (i < len) {
-            keys[lo + i] = row_part | (uint64_t)(x[e] >> IDX_BITS);
+            keys_out[lo + i] = row_part | (uint64_t)(x[e] >> IDX_BITS);
             perm[lo + i] = (uint32_t)(lo + (uint32_t)(x[e] & (W)((1u << IDX_BITS) - 1u)));
         }
     }
@@ -459,9 +460,9 @@ __device__ __forceinline__ void sort_task_segment_regs(uint64_t *__restrict__ ke
 // (two launches over the same list -- segments of <= 512 words in a kernel of their own at full occupancy -- were measured: the second
 // launch costs more than the occupancy returns, cage-like T_5 195 -> 220 us)
 template <typename W>
-__global__ __launch_bounds__(kThreads) void segsort_tasks_wave_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, const int *__restrict__ segs,
-                                                                      uint32_t nseg, uint64_t n, const uint32_t *__restrict__ list, uint32_t count,
-                                                                      uint64_t col_mask)
+__global__ __launch_bounds__(kThreads) void segsort_tasks_wave_kernel(const uint64_t *keys, uint64_t *keys_out, uint32_t *__restrict__ perm,
+                                                                      const int *__restrict__ segs, uint32_t nseg, uint64_t n,
+                                                                      const uint32_t *__restrict__ list, uint32_t count, uint64_t col_mask)
 {
     const uint32_t li = blockIdx.x * 4 + (uint32_t)wave_id();
     if (li >= count) return;
@@ -469,12 +470,12 @@ __global__ __launch_bounds__(kThreads) void segsort_tasks_wave_kernel(uint64_t *
     const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
     const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hi - lo));
     const int lane = lane_id();
-    if (len <= 128) sort_task_segment_regs<W, 2, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
-    else if (len <= 256) sort_task_segment_regs<W, 4, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
-    else if (len <= 512) sort_task_segment_regs<W, 8, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
-    else if (len <= 1024) sort_task_segment_regs<W, 16, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
-    else if (sizeof(W) == 8 || len <= 2048) sort_task_segment_regs<W, 32, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
-    else if constexpr (sizeof(W) == 4) sort_task_segment_regs<W, 64, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);  // 64 words per lane
+    if (len <= 128) sort_task_segment_regs<W, 2, kTaskBlockIdxBits>(keys, keys_out, perm, lo, len, col_mask, lane);
+    else if (len <= 256) sort_task_segment_regs<W, 4, kTaskBlockIdxBits>(keys, keys_out, perm, lo, len, col_mask, lane);
+    else if (len <= 512) sort_task_segment_regs<W, 8, kTaskBlockIdxBits>(keys, keys_out, perm, lo, len, col_mask, lane);
+    else if (len <= 1024) sort_task_segment_regs<W, 16, kTaskBlockIdxBits>(keys, keys_out, perm, lo, len, col_mask, lane);
+    else if (sizeof(W) == 8 || len <= 2048) sort_task_segment_regs<W, 32, kTaskBlockIdxBits>(keys, keys_out, perm, lo, len, col_mask, lane);
+    else if constexpr (sizeof(W) == 4) sort_task_segment_regs<W, 64, kTaskBlockIdxBits>(keys, keys_out, perm, lo, len, col_mask, lane);  // 64 words per lane
 }
 
 // the same sort without segment lists: wave i takes segment i of the run-start array.  For products whose block-row segments are known
@@ -493,15 +494,15 @@ __global__ __launch_bounds__(kThreads) void segsort_tasks_direct_kernel(uint64_t
     const int lane = lane_id();
     if (len == 1) {
         if (lane == 0) perm[lo] = (uint32_t)lo;
-    } else if (len <= 128) sort_task_segment_regs<W, 2, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
-    else if (len <= 256) sort_task_segment_regs<W, 4, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
-    else if (len <= 512) sort_task_segment_regs<W, 8, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
-    else if (len <= 1024) sort_task_segment_regs<W, 16, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
-    else if (len <= 2048) sort_task_segment_regs<W, 32, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+    } else if (len <= 128) sort_task_segment_regs<W, 2, kTaskBlockIdxBits>(keys, keys, perm, lo, len, col_mask, lane);
+    else if (len <= 256) sort_task_segment_regs<W, 4, kTaskBlockIdxBits>(keys, keys, perm, lo, len, col_mask, lane);
+    else if (len <= 512) sort_task_segment_regs<W, 8, kTaskBlockIdxBits>(keys, keys, perm, lo, len, col_mask, lane);
+    else if (len <= 1024) sort_task_segment_regs<W, 16, kTaskBlockIdxBits>(keys, keys, perm, lo, len, col_mask, lane);
+    else if (len <= 2048) sort_task_segment_regs<W, 32, kTaskBlockIdxBits>(keys, keys, perm, lo, len, col_mask, lane);
     else {
         if constexpr (sizeof(W) == 4) {
             if (len <= 4096) {
-                sort_task_segment_regs<W, 64, kTaskBlockIdxBits>(keys, perm, lo, len, col_mask, lane);
+                sort_task_segment_regs<W, 64, kTaskBlockIdxBits>(keys, keys, perm, lo, len, col_mask, lane);
                 return;
             }
         }
@@ -510,13 +511,14 @@ __global__ __launch_bounds__(kThreads) void segsort_tasks_direct_kernel(uint64_t
 }
 
 template <typename W>
-__global__ __launch_bounds__(512) void segsort_tasks_block_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, const int *__restrict__ segs,
-                                                                  uint32_t nseg, uint64_t n, const uint32_t *__restrict__ list, uint64_t col_mask)
+__global__ __launch_bounds__(512) void segsort_tasks_block_kernel(const uint64_t *keys, uint64_t *keys_out, uint32_t *__restrict__ perm,
+                                                                  const int *__restrict__ segs, uint32_t nseg, uint64_t n,
+                                                                  const uint32_t *__restrict__ list, uint64_t col_mask)
 {
     __shared__ W s_a[kBlockSegMax];
     const uint32_t s = list[blockIdx.x];
     const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
-    sort_task_segment<W, 512, true, kTaskBlockIdxBits>(s_a, keys, perm, lo, (uint32_t)(hi - lo), 1024u, col_mask, threadIdx.x);
+    sort_task_segment<W, 512, true, kTaskBlockIdxBits>(s_a, keys, keys_out, perm, lo, (uint32_t)(hi - lo), 1024u, col_mask, threadIdx.x);
 }
 
 // ---- segments beyond a wave's / workgroup's capacity: pieces + merge passes --------------------------------------------------------
@@ -625,6 +627,205 @@ __global__ __launch_bounds__(kThreads) void merge_pass_kernel(const uint64_t *__
     }
 }
 
+// ---- long segments, second form (round 4): segmented LSD radix sort on the column bits --------------------------------------------
+// The merge passes above move every element of every long segment ceil(log2(longest / cap)) times: R-MAT scale 22 x 1 has 568 M of its
+// 690 M tasks in segments beyond a wave's capacity, the longest of 4 M tasks: 10 passes of 13.6 GB each (38 ms of a 120 ms product)
+// after the piece sort.  Inside a segment only the column varies (jbits <= 21 bits whenever the narrow words apply): ceil(jbits / 7) stable
+// counting passes order it, whatever its length, and the pieces need no sort of their own.
+//   work item  = a tile of kSegRadixTile consecutive elements of ONE long segment (a workgroup of 8 waves; wave w owns elements 512 w ..)
+//   count pass = digit histogram of the tile -> table[segment's first tile * RADIX + digit * tiles_of_segment + tile]: DIGIT-MAJOR inside
+//                the segment, so that one exclusive scan of the whole table (minus its value at the segment's first entry) is the
+//                place of (digit, tile) inside the segment
+//   scatter    = rank of an element among the tile's elements of its digit: 64 elements per wave and round, peers by one ballot per
+//                digit bit, earlier rounds through per-wave counters in LDS, earlier waves by a prefix over those counters; the tile
+//                is laid out by digit in LDS first, so that neighbouring lanes write neighbouring words (runs of T / RADIX on average)
+// What moves is the composite word (column << 32) | source position (8 bytes; the first pass forms it from the keys, the last pass
+// writes keys and permutation apart); the passes alternate between the key array and its scratch partner, and the short segments are
+// sorted by the wave / workgroup kernels INTO the array the last pass writes, so nothing is copied home.
+constexpr uint32_t kSegRadixTile = 4096;
+constexpr int kSegRadixThreads = 512, kSegRadixWaves = kSegRadixThreads / 64, kSegRadixBits = 7, kSegRadixBins = 1 << kSegRadixBits;
+constexpr uint32_t kSegRadixRounds = kSegRadixTile / kSegRadixThreads;  // elements per lane
+
+struct RadixWork {
+    uint32_t lo, len, tile, first;  // segment start and length, tile inside the segment, index of the segment's first work item
+    uint64_t row_part;              // the segment's block-row bits of the key: the composite words do not carry them
+};
+struct RadixTilesIn {
+    SegClassify c;
+    __device__ uint32_t operator()(uint64_t s) const
+    {
+        if (s >= c.nseg) return 0u;
+        const uint32_t l = c.len(s);
+        return c.is_long(l) ? (l + kSegRadixTile - 1u) / kSegRadixTile : 0u;
+    }
+};
+struct RadixTilesOut {
+    SegClassify c;
+    const uint64_t *keys;
+    uint64_t col_mask;
+    RadixWork *work;
+    uint32_t *stats;  // [0] work items, [1] longest segment, [2] elements in long segments
+    __device__ void operator()(uint64_t s, uint32_t ex, uint32_t cnt) const
+    {
+        if (s == c.nseg) { stats[0] = ex; return; }
+        if (!cnt) return;
+        const uint32_t lo = (uint32_t)c.segs[s], len = c.len(s);
+        const uint64_t row_part = keys[lo] & ~col_mask;
+        for (uint32_t t = 0; t < cnt; t++) work[ex + t] = RadixWork{lo, len, t, ex, row_part};
+        atomicMax(stats + 1, len);
+        atomicAdd(stats + 2, len);
+    }
+};
+
+template <bool FIRST>
+__device__ __forceinline__ uint64_t radix_word(const uint64_t *__restrict__ src, uint64_t i, uint64_t col_mask)
+{
+    const uint64_t k = src[i];
+    return FIRST ? (((k & col_mask) << 32) | (uint64_t)(uint32_t)i) : k;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kSegRadixThreads) void segradix_count_kernel(const uint64_t *__restrict__ src, const RadixWork *__restrict__ work,
+                                                                       uint32_t *__restrict__ table, int shift, int bits, uint64_t col_mask)
+{
+    __shared__ uint32_t h[kSegRadixBins];
+    const RadixWork w = work[blockIdx.x];
+    const uint32_t radix = 1u << bits, o0 = w.tile * kSegRadixTile, n_t = min(kSegRadixTile, w.len - o0);
+    if (threadIdx.x < radix) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint64_t base = (uint64_t)w.lo + o0;
+#pragma unroll
+    for (uint32_t r = 0; r < kSegRadixRounds; r++) {
+        const uint32_t e = r * kSegRadixThreads + threadIdx.x;
+        if (e < n_t) {
+            const uint64_t k = src[base + e];
+            const uint32_t col = FIRST ? (uint32_t)(k & col_mask) : (uint32_t)(k >> 32);
+            atomicAdd(&h[(col >> shift) & (radix - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t ntiles = (w.len + kSegRadixTile - 1u) / kSegRadixTile;
+    if (threadIdx.x < radix) table[(uint64_t)w.first * radix + (uint64_t)threadIdx.x * ntiles + w.tile] = h[threadIdx.x];
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(kSegRadixThreads) void segradix_scatter_kernel(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst,
+                                                                         uint32_t *__restrict__ perm_out, const RadixWork *__restrict__ work,
+                                                                         const uint32_t *__restrict__ table, int shift, int bits, uint64_t col_mask)
+{
+    __shared__ uint64_t buf[kSegRadixTile];
+    __shared__ uint32_t cnt[kSegRadixWaves][kSegRadixBins];
+    __shared__ uint32_t dstart[kSegRadixBins], gbase[kSegRadixBins];
+    const RadixWork w = work[blockIdx.x];
+    const uint32_t radix = 1u << bits, o0 = w.tile * kSegRadixTile, n_t = min(kSegRadixTile, w.len - o0);
+    const int lane = lane_id(), wave = wave_id();
+    const uint64_t base = (uint64_t)w.lo + o0;
+    for (uint32_t i = threadIdx.x; i < kSegRadixWaves * kSegRadixBins; i += kSegRadixThreads) (&cnt[0][0])[i] = 0u;
+    // wave `wave` owns elements wave * 512 + r * 64 + lane: source order = (wave, round, lane)
+    uint64_t c[kSegRadixRounds];
+#pragma unroll
+    for (uint32_t r = 0; r < kSegRadixRounds; r++) {
+        const uint32_t e = (uint32_t)wave * (kSegRadixTile / kSegRadixWaves) + r * 64u + (uint32_t)lane;
+        c[r] = e < n_t ? radix_word<FIRST>(src, base + e, col_mask) : ~0ull;
+    }
+    __syncthreads();
+    uint32_t rank[kSegRadixRounds];
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (uint32_t r = 0; r < kSegRadixRounds; r++) {
+        const uint32_t e = (uint32_t)wave * (kSegRadixTile / kSegRadixWaves) + r * 64u + (uint32_t)lane;
+        const bool valid = e < n_t;
+        const uint32_t d = (uint32_t)(c[r] >> (32 + shift)) & (radix - 1u);
+        uint64_t m = __ballot(valid);
+        for (int b = 0; b < bits; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const uint32_t prior = cnt[wave][d];
+        const uint32_t below = (uint32_t)__popcll(m & lt);
+        rank[r] = prior + below;
+        if (valid && (m >> lane) == 1ull) cnt[wave][d] = prior + below + 1u;  // the last lane of the digit's peers leaves the new count
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    const uint32_t ntiles = (w.len + kSegRadixTile - 1u) / kSegRadixTile;
+    if (threadIdx.x < radix) {
+        uint32_t acc = 0u;
+#pragma unroll
+        for (int v = 0; v < kSegRadixWaves; v++) {
+            const uint32_t t = cnt[v][threadIdx.x];
+            cnt[v][threadIdx.x] = acc;
+            acc += t;
+        }
+        dstart[threadIdx.x] = acc;
+        const uint64_t tb = (uint64_t)w.first * radix;
+        gbase[threadIdx.x] = table[tb + (uint64_t)threadIdx.x * ntiles + w.tile] - table[tb];
+    } else if (threadIdx.x < (uint32_t)kSegRadixBins) {
+        dstart[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive scan of the tile's digit totals: two digits per lane
+        const uint32_t a = dstart[2 * lane], b = dstart[2 * lane + 1];
+        const uint32_t inc = wave_inclusive_sum(a + b);
+        dstart[2 * lane] = inc - a - b;
+        dstart[2 * lane + 1] = inc - b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < kSegRadixRounds; r++) {
+        const uint32_t e = (uint32_t)wave * (kSegRadixTile / kSegRadixWaves) + r * 64u + (uint32_t)lane;
+        if (e < n_t) {
+            const uint32_t d = (uint32_t)(c[r] >> (32 + shift)) & (radix - 1u);
+            buf[dstart[d] + cnt[wave][d] + rank[r]] = c[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < kSegRadixRounds; r++) {
+        const uint32_t i = r * kSegRadixThreads + threadIdx.x;
+        if (i < n_t) {
+            const uint64_t x = buf[i];
+            const uint32_t d = (uint32_t)(x >> (32 + shift)) & (radix - 1u);
+            const uint64_t dest = (uint64_t)w.lo + gbase[d] + (i - dstart[d]);
+            if (LAST) {
+                dst[dest] = w.row_part | (x >> 32);
+                perm_out[dest] = (uint32_t)x;
+            } else {
+                dst[dest] = x;
+            }
+        }
+    }
+}
+
+template <bool FIRST, bool LAST>
+void segradix_pass(const uint64_t *src, uint64_t *dst, uint32_t *perm_out, const RadixWork *work, uint32_t n_work, DevBuf<uint32_t> &table, int shift, int bits,
+                   uint64_t col_mask, hipStream_t st)
+{
+    const uint64_t entries = (uint64_t)n_work << bits;
+    hipLaunchKernelGGL((segradix_count_kernel<FIRST>), dim3(n_work), dim3(kSegRadixThreads), 0, st, src, work, table.p, shift, bits, col_mask);
+    BMSP_CHECK_LAUNCH();
+    device_exclusive_scan<uint32_t>(PtrIn<uint32_t>{table.p}, PtrOut<uint32_t>{table.p}, entries, st);
+    hipLaunchKernelGGL((segradix_scatter_kernel<FIRST, LAST>), dim3(n_work), dim3(kSegRadixThreads), 0, st, src, dst, perm_out, work, (const uint32_t *)table.p, shift,
+                       bits, col_mask);
+    BMSP_CHECK_LAUNCH();
+}
+
+struct CopyLoneKeys {  // segments of one element when the sorted keys are written to the scratch array
+    const int *segs;
+    uint32_t nseg;
+    uint64_t n;
+    const uint64_t *keys;
+    uint64_t *keys_out;
+    uint32_t *perm;
+    __device__ void operator()(uint64_t s) const
+    {
+        if (s >= nseg) return;
+        const uint64_t lo = (uint64_t)segs[s], hi = s + 1 < nseg ? (uint64_t)segs[s + 1] : n;
+        if (hi == lo + 1) keys_out[lo] = keys[lo];
+    }
+};
+
 struct CopyKeyPerm {
     const uint64_t *ks;
     const uint32_t *ps;
@@ -635,13 +836,15 @@ struct CopyKeyPerm {
 
 // sorts the segments of (keys, perm) -- keys in place, perm[i] = source position of the element now at i.  `alt_keys` is a scratch array
 // of n keys the caller provides (the ping-pong partner), `perm_alt` an empty buffer the merge passes allocate.  Returns false when the
-// call is not handled (nothing modified).  *in_alt = true: the result sits in (alt_keys, perm_alt) -- an odd number of merge passes over a
-// list in which EVERY segment was long: nothing has to be copied home, the caller flips its buffers.
+// call is not handled (nothing modified).  *in_alt = true: the sorted KEYS sit in alt_keys (the caller flips its buffers) -- an odd number
+// of radix passes (the short segments were sorted into alt_keys as well), or an odd number of merge passes over a list in which EVERY
+// segment was long; *perm_in_alt says the same of the permutation (merge passes only: the radix passes write `perm` whatever their number).
 template <typename W>
 bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *segs, uint32_t nseg, int jbits, hipStream_t st, uint64_t *alt_keys = nullptr,
-                       DevBuf<uint32_t> *perm_alt = nullptr, bool *in_alt = nullptr)
+                       DevBuf<uint32_t> *perm_alt = nullptr, bool *in_alt = nullptr, bool *perm_in_alt = nullptr, int *long_mode = nullptr)
 {
     if (in_alt) *in_alt = false;
+    if (perm_in_alt) *perm_in_alt = false;
     if (nseg >= (1u << 21)) return false;
     const uint32_t cap = sizeof(W) == 4 ? 2 * kTaskWaveMax : kTaskWaveMax;  // 32-bit words: a wave holds a 4096-word segment in registers
     SegClassify cls{segs, nseg, n, cap};
@@ -651,8 +854,42 @@ bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *se
     const uint64_t t = tot.wait(st);
     const uint32_t n_wave = (uint32_t)(t & 0x1fffffu), n_block = (uint32_t)((t >> 21) & 0x1fffffu), n_long = (uint32_t)(t >> 42);
     const uint64_t col_mask = (1ull << jbits) - 1ull;
-    if (n_long) {
+    uint64_t *keys_out = keys;  // where the short segments' kernels write
+    bool radix_done = false;
+    const char *radix_env = getenv("BMSP_SEGSORT_RADIX");  // 0: merge passes, 1: radix passes whatever the lengths (tests, A/B runs)
+    const int radix_mode = radix_env ? atoi(radix_env) : -1;
+    if (n_long && alt_keys && in_alt && perm_in_alt && radix_mode != 0 && jbits <= 32) {
+        // work items of the long segments, the longest of them and what they hold
+        const uint64_t max_tiles = n / kSegRadixTile + (uint64_t)n_long + 1;
+        DevBuf<RadixWork> work(max_tiles);
+        DevBuf<uint32_t> stats(3);
+        BMSP_HIP(hipMemsetAsync(stats.p, 0, 12, st));
+        device_exclusive_scan<uint32_t>(RadixTilesIn{cls}, RadixTilesOut{cls, keys, col_mask, work.p, stats.p}, (uint64_t)nseg + 1, st);
+        uint32_t hs[3];
+        read_back_bytes(hs, stats.p, 12, st);
+        const uint32_t n_work = hs[0], max_len = hs[1];
+        // three merge passes cost what the radix passes cost: segments just beyond a wave's capacity stay with pieces + merge
+        if (n_work && (radix_mode == 1 || max_len > 8u * cap)) {
+            const int passes = std::max(1, (jbits + kSegRadixBits - 1) / kSegRadixBits), bits = std::max(1, (jbits + passes - 1) / passes);
+            DevBuf<uint32_t> table((uint64_t)n_work << bits);
+            for (int p = 0; p < passes; p++) {
+                const uint64_t *src = (p & 1) ? alt_keys : keys;
+                uint64_t *dst = (p & 1) ? keys : alt_keys;
+                const bool first = p == 0, last = p == passes - 1;
+                if (first && last) segradix_pass<true, true>(src, dst, perm, work.p, n_work, table, p * bits, bits, col_mask, st);
+                else if (first) segradix_pass<true, false>(src, dst, perm, work.p, n_work, table, p * bits, bits, col_mask, st);
+                else if (last) segradix_pass<false, true>(src, dst, perm, work.p, n_work, table, p * bits, bits, col_mask, st);
+                else segradix_pass<false, false>(src, dst, perm, work.p, n_work, table, p * bits, bits, col_mask, st);
+            }
+            if (passes & 1) { keys_out = alt_keys; *in_alt = true; }
+            radix_done = true;
+            if (long_mode) *long_mode = BMSP_SORT_LONG_RADIX;
+            BMSP_HIP(hipStreamSynchronize(st));  // work list and table go back to the pool
+        }
+    }
+    if (n_long && !radix_done) {
         if (!perm_alt || !alt_keys || getenv("BMSP_SEGSORT_NO_MERGE")) return false;
+        if (long_mode) *long_mode = BMSP_SORT_LONG_MERGE;
         // 1. pieces of at most `cap` words; the pieces are sorted like ordinary segments
         const uint64_t max_pieces = (uint64_t)nseg + n / cap + 1;
         if (max_pieces >= (1u << 21)) return false;
@@ -684,8 +921,8 @@ bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *se
             std::swap(ks, kd); std::swap(ps, pd);
             passes++;
         }
-        if ((passes & 1) && all_long && in_alt) {
-            *in_alt = true;  // every element went through the passes: the scratch pair holds the whole result
+        if ((passes & 1) && all_long && in_alt && perm_in_alt) {
+            *in_alt = *perm_in_alt = true;  // every element went through the passes: the scratch pair holds the whole result
         } else if (passes & 1) {
             // the long segments' result sits in (alt_keys, perm_alt): bring it home tile by tile (a "merge" of runs as long as the segment copies)
             hipLaunchKernelGGL(merge_pass_kernel, dim3(n_work), dim3(kThreads), 0, st, ks, ps, kd, pd, work.p, 0x40000000u, col_mask);
@@ -695,12 +932,18 @@ bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *se
         return true;
     }
     if (n_wave) {
-        hipLaunchKernelGGL((segsort_tasks_wave_kernel<W>), dim3((n_wave + 3) / 4), dim3(kThreads), 0, st, keys, perm, segs, nseg, n, wave_list.p, n_wave, col_mask);
+        hipLaunchKernelGGL((segsort_tasks_wave_kernel<W>), dim3((n_wave + 3) / 4), dim3(kThreads), 0, st, (const uint64_t *)keys, keys_out, perm, segs, nseg, n,
+                           wave_list.p, n_wave, col_mask);
         BMSP_CHECK_LAUNCH();
     }
     if (n_block) {
-        hipLaunchKernelGGL((segsort_tasks_block_kernel<W>), dim3(n_block), dim3(512), 0, st, keys, perm, segs, nseg, n, block_list.p, col_mask);
+        hipLaunchKernelGGL((segsort_tasks_block_kernel<W>), dim3(n_block), dim3(512), 0, st, (const uint64_t *)keys, keys_out, perm, segs, nseg, n, block_list.p,
+                           col_mask);
         BMSP_CHECK_LAUNCH();
+    }
+    if (keys_out != keys) {
+        // segments of one element (no class, no kernel) and anything in front of the first segment: the key itself
+        device_for_each(CopyLoneKeys{segs, nseg, n, keys, keys_out, perm}, (uint64_t)nseg + 1, st);
     }
     return true;
 }
@@ -727,8 +970,9 @@ void segsort_check_violation()
 }
 
 bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals, uint64_t n, int jbits, hipStream_t st, uint64_t max_seg_bound,
-                             uint64_t seg_count_bound)
+                             uint64_t seg_count_bound, int *long_mode)
 {
+    if (long_mode) *long_mode = 0;
     if (n >= (1ull << 31)) return false;
     // segments = runs of equal block-row (reference: :982-1004).  Inside a run the row part of the packed key is
     // constant, so comparing whole keys orders by column: no masking pass is needed.
@@ -759,12 +1003,12 @@ bool segsort_tasks_by_column(PingPong<uint64_t> &keys, PingPong<uint64_t> &vals,
     device_exclusive_scan<uint32_t>(RunHead{keys.cur, n, jbits}, EmitRunStarts{keys.cur, n, jbits, segs.p, cnt.dev(), nullptr}, n + 1, st);
     const uint32_t nseg = cnt.wait(st);
     DevBuf<uint32_t> perm_alt;
-    bool in_alt = false;
-    const bool ok = narrow ? segsort_tasks_lds<uint32_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st, keys.alt, &perm_alt, &in_alt)
-                           : segsort_tasks_lds<uint64_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st, keys.alt, &perm_alt, &in_alt);
+    bool in_alt = false, perm_in_alt = false;
+    const bool ok = narrow ? segsort_tasks_lds<uint32_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st, keys.alt, &perm_alt, &in_alt, &perm_in_alt, long_mode)
+                           : segsort_tasks_lds<uint64_t>(keys.cur, perm.p, n, segs.p, nseg, jbits, st, keys.alt, &perm_alt, &in_alt, &perm_in_alt, long_mode);
     if (!ok) return false;  // not handled: the caller takes the global sort
     if (in_alt) keys.flip();
-    device_for_each(GatherVals<uint64_t>{vals.cur, in_alt ? perm_alt.p : perm.p, vals.alt}, n, st);
+    device_for_each(GatherVals<uint64_t>{vals.cur, perm_in_alt ? perm_alt.p : perm.p, vals.alt}, n, st);
     vals.flip();
     BMSP_HIP(hipStreamSynchronize(st));  // perm_alt goes back to the pool
     return true;

@@ -1249,7 +1249,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
                                (mode == BMSP_SORT_AUTO && avg_seg >= 4 && (avg_seg <= seg_avg_max || (seg_bound > 0 && seg_bound <= 16384)));
     S->sort_path = 0;
     if (n_tasks) {
-        if (try_segmented && segsort_tasks_by_column(kk, vv, n_tasks, jbits, st, seg_bound, a_block_rows)) {
+        if (try_segmented && segsort_tasks_by_column(kk, vv, n_tasks, jbits, st, seg_bound, a_block_rows, &S->sort_long)) {
             S->sort_path = 1;
             tm.mark(8);
         } else {

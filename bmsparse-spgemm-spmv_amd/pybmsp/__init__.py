@@ -44,11 +44,11 @@ class BmspError(RuntimeError):
 class SpgemmStats(C.Structure):
     _fields_ = [("task_list_size", C.c_int64), ("bmp_reduction", C.c_int64), ("surviving_tasks", C.c_int64),
                 ("c_blocks", C.c_int64), ("c_nnz", C.c_int64), ("t_us", C.c_double * 10),
-                ("sort_path", C.c_int), ("mac_kernel", C.c_int), ("mac_variant", C.c_int), ("reserved", C.c_int)]
+                ("sort_path", C.c_int), ("mac_kernel", C.c_int), ("mac_variant", C.c_int), ("sort_long", C.c_int)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k in ("task_list_size", "bmp_reduction", "surviving_tasks", "c_blocks", "c_nnz",
-                                           "sort_path", "mac_kernel", "mac_variant")}
+                                           "sort_path", "mac_kernel", "mac_variant", "sort_long")}
         d["t_us"] = list(self.t_us)
         return d
 

@@ -193,10 +193,13 @@ typedef struct {
                               * block-row by block-row in LDS (BMSP_SORT_PATH_ROWMERGE; T_3 then holds the whole symbolic pass) */
     int mac_kernel;          /* which block-MAC kernel ran (see tc_version) */
     int mac_variant;         /* which implementation of it: BMSP_MAC_* below */
-    int reserved;
+    int sort_long;           /* sort_path 1 only: how block-rows of more tasks than one wave sorts in registers were ordered -- 0 = there were
+                              * none, 1 = pieces + merge passes, 2 = stable counting passes on the column bits (BMSP_SORT_LONG_*) */
 } bmsp_spgemm_stats;
 /* implementations behind one tc_version (the launcher picks by the product's shape; all give the tc_version's numerics) */
 #define BMSP_SORT_PATH_ROWMERGE 2
+#define BMSP_SORT_LONG_MERGE 1
+#define BMSP_SORT_LONG_RADIX 2
 #define BMSP_SORT_PATH_ROWWINDOW 3 /* none either: block-rows of C formed window by window of block columns in dense LDS tables (operands with hub block-rows) */
 #define BMSP_MAC_DEFAULT 0 /* the only kernel of that tc_version (V15 vector-ALU kernels, K = 16 MFMA kernels) */
 #define BMSP_MAC_STAGED 1  /* tc 4: K = 32 MFMA, operands staged through LDS per task (sparse task lists) */

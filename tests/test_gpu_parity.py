@@ -575,19 +575,43 @@ def test_mfma32_block_mac_paths(oracle, bmsp, monkeypatch, case, b_dense, quota)
         np.testing.assert_allclose(vn, vo, rtol=2e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("long_sort", ["merge", "radix"])
 @pytest.mark.parametrize("wide", [False, True])
-@pytest.mark.parametrize("case", ["two_pieces", "three_pieces", "rmat_hubs"])
-def test_spgemm_long_segments_merge(oracle, bmsp, monkeypatch, case, wide):
+@pytest.mark.parametrize("case", ["two_pieces", "three_pieces", "rmat_hubs", "wide_cols"])
+def test_spgemm_long_segments_merge(oracle, bmsp, monkeypatch, case, wide, long_sort):
     """T_5, segmented path, block-rows whose task segment exceeds what a wave sorts in registers (4096 words, 2048 with 64-bit sort
-    words): the segment is cut into pieces, the pieces are sorted like ordinary segments and merged by merge-path passes (one pass +
-    the copy back for two pieces, two passes for three or four, a hub-row mix on R-MAT).  The fp32 V15 values are compared BIT FOR BIT:
-    they depend on the order of the tasks inside every C tile, i.e. on the sort being stable across piece boundaries."""
+    words).  `merge`: the segment is cut into pieces, the pieces are sorted like ordinary segments and merged by merge-path passes (one
+    pass + the copy back for two pieces, two passes for three or four, a hub-row mix on R-MAT).  `radix` (round 4, what long hub
+    segments take by default): stable counting passes on 7 column bits at a time over tiles of 4096 -- one pass for the narrow B's, two
+    on R-MAT, three for `wide_cols` (36 000 block columns), with a ragged last tile, two long segments side by side and short segments
+    around them written into the other array when the pass count is odd.  The fp32 V15 values are compared BIT FOR BIT: they depend
+    on the order of the tasks inside every C tile, i.e. on the sort being stable across piece / tile boundaries."""
     from pybmsp import gen
     if wide:
         monkeypatch.setenv("BMSP_SEGSORT_WIDE", "1")
+    monkeypatch.setenv("BMSP_SEGSORT_RADIX", "1" if long_sort == "radix" else "0")
     if case == "rmat_hubs":
         n, _, r, c, v = gen.rmat(12, 8)
         A = Bc = (n, n, r, c, v)
+    elif case == "wide_cols":
+        # block-rows 0 and 1 of A full over 300 block columns (6000 tasks each), block-rows 2 .. 5 short (one, two, 40 and 300 tiles);
+        # every block-row of B: 20 one-value tiles, 12 of them at random block columns of 36 000, 8 at columns shared by all rows
+        # (C tiles with 300 tasks whose order the sort must keep)
+        rng = np.random.default_rng(17)
+        nk, nbc = 8 * 300, 36000
+        r = np.repeat(np.arange(16), nk); c = np.tile(np.arange(nk), 16)
+        extra_r = np.concatenate([[16], [24, 24], np.full(40, 32), np.full(300, 40)])
+        extra_c = np.concatenate([[8 * 7], [8 * 3, 8 * 250], 8 * np.arange(40) * 7, 8 * np.arange(300)])
+        r = np.concatenate([r, extra_r]); c = np.concatenate([c, extra_c])
+        A = (48, nk, r, c, np.sin(r * 7.0 + c))
+        shared = rng.choice(nbc, 8, replace=False)
+        rb, cb = [], []
+        for br in range(300):
+            cols = np.unique(np.concatenate([shared, rng.choice(nbc, 12, replace=False)]))
+            for k in range(8):
+                rb.append(np.full(cols.size, 8 * br + k)); cb.append(8 * cols + (k + br) % 8)
+        rb = np.concatenate(rb); cb = np.concatenate(cb)
+        Bc = (nk, 8 * nbc, rb, cb, np.cos(rb * 3.0 + cb))
     else:
         # 2 block-rows x 300 block-columns of A, all full; B's block-rows hold 20 / 40 tiles: 6000 / 12000 tasks per block-row of C
         nb_cols = 20 if case == "two_pieces" else 40
@@ -600,6 +624,25 @@ def test_spgemm_long_segments_merge(oracle, bmsp, monkeypatch, case, wide):
     assert st["sort_path"] == 1, st          # the segmented path took it (before round 3 a long segment fell back to the radix sort)
     st2 = check_spgemm(oracle, bmsp, A, Bc, 1, 1, 4)
     assert st2["sort_path"] == 1
+
+
+@pytest.mark.parametrize("scale,ef", [(15, 8), (18, 1)])
+def test_spgemm_long_segments_radix_by_default(bmsp, monkeypatch, scale, ef):
+    """Hub block-rows on the expand-sort-compress pipeline (R-MAT, explicit segmented sort, no row-merge / window passes): segments of
+    10^5 .. 10^6 tasks take the counting passes without being asked (stats.sort_long = 2; two passes at scale 15, three at 18), and C --
+    keys, bitmaps, offsets and the fp32 V15 values, which depend on the task order inside every C tile -- equals the merge passes' C bit
+    for bit.  (The merge form is pinned against the oracle by test_spgemm_long_segments_merge.)"""
+    from pybmsp import gen
+    n, _, r, c, v = gen.rmat(scale, ef)
+    a = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, dtype=0)
+    b = bmsp.BmSpMatrix.from_coo(n, n, r, c, v, transposed=True, dtype=0)
+    c_radix, st = bmsp.spgemm(a, b, mode=1, tc_version=5)
+    assert st["sort_path"] == 1 and st["sort_long"] == 2, st
+    monkeypatch.setenv("BMSP_SEGSORT_RADIX", "0")
+    c_merge, st0 = bmsp.spgemm(a, b, mode=1, tc_version=5)
+    assert st0["sort_path"] == 1 and st0["sort_long"] == 1, st0
+    for x, y in zip(c_radix.host_arrays(), c_merge.host_arrays()):
+        np.testing.assert_array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8))
 
 
 def test_mfma_f32_accumulation_order(bmsp):
