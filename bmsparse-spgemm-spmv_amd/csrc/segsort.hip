@@ -868,8 +868,9 @@ bool segsort_tasks_lds(uint64_t *keys, uint32_t *perm, uint64_t n, const int *se
         uint32_t hs[3];
         read_back_bytes(hs, stats.p, 12, st);
         const uint32_t n_work = hs[0], max_len = hs[1];
-        // three merge passes cost what the radix passes cost: segments just beyond a wave's capacity stay with pieces + merge
-        if (n_work && (radix_mode == 1 || max_len > 8u * cap)) {
+        // segments of up to four pieces stay with pieces + merge (two passes of 24 bytes per element after the piece sort; the counting
+        // passes move 24 - 28 bytes per element and pass, two or three times, without a piece sort)
+        if (n_work && (radix_mode == 1 || max_len > 4u * cap)) {
             const int passes = std::max(1, (jbits + kSegRadixBits - 1) / kSegRadixBits), bits = std::max(1, (jbits + passes - 1) / passes);
             DevBuf<uint32_t> table((uint64_t)n_work << bits);
             for (int p = 0; p < passes; p++) {

@@ -1231,20 +1231,21 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
     PingPong<uint64_t> kk{k0.p, k1.p}, vv{v0.p, v1.p};
     // The tasks leave the expansion grouped by block-row of A (A's blocks are key-ordered), so only the column bits need
     // sorting inside each block-row segment.  The segmented sort keeps a whole segment in LDS (segsort.hip); it wins when
-    // segments are long enough to fill a wave yet none exceeds a workgroup's LDS (cage-like rows: 289 vs 410 us; banded, 9 tasks
-    // per block-row: 92 vs 121 us); hub rows (power-law) are faster through the global radix sort on the packed key.  AUTO decides on the average
-    // segment length -- the reference decides on the task count alone (:963) -- and falls back when a hub row shows up.
+    // segments are long enough to fill a wave (cage-like rows: 289 vs 410 us; banded, 9 tasks per block-row: 92 vs 121 us) and -- since
+    // round 4, with counting passes on the column bits for the hub rows of power-law operands -- whatever their longest is.  AUTO
+    // decides on the average segment length; the reference decides on the task count alone (:963).
     const uint64_t a_block_rows = (uint64_t)A->num_block_rows();
     const uint64_t avg_seg = n_tasks / (a_block_rows ? a_block_rows : 1);
     // a block-row of C collects at most (most blocks in a block-row of A) x (most blocks in a block-row of B) tasks: when that fits a
     // wave's register sort, T_5 runs without a single read-back (per-matrix maxima, cached: ensure_row_stats)
     const uint64_t seg_bound = (uint64_t)std::max<int64_t>(A->max_row_blocks, 0) * (uint64_t)std::max<int64_t>(B->max_row_blocks, 0);
-    // Segments beyond a wave's 4096 words are sorted in pieces and merged (segsort.hip).  Measured: that beats the global radix sort when
-    // every segment needs at most a couple of merge passes (dense-tile ceiling, 4225 tasks per block-row: 2.9 vs 3.8 ms) and loses to it on
-    // power-law rows (R-MAT 2^16, hub segments of 10^5 tasks: 4.5 vs 2.8 ms) -- so AUTO takes it when the operands' row maxima bound every
-    // segment by 4 pieces; BMSP_SEG_AVG_MAX moves the average-length bound for experiments
+    // Segments beyond a wave's 4096 words: pieces + merge passes while two passes do (dense-tile ceiling, 4225 tasks per block-row: 2.9
+    // vs 3.8 ms for the global radix sort), stable counting passes on the column bits beyond that (segsort.hip).  Before the counting
+    // passes hub rows lost to the global sort (R-MAT 2^16, segments of 10^5 tasks, merge passes: 4.5 vs 2.8 ms) and AUTO kept products
+    // of more than 2048 tasks per block-row away from the segmented path; with them it wins there too (R-MAT 2^16 x 8: T_5 1.70 vs 2.78 ms,
+    // 2^20 x 2: 9.8 vs 20.2 ms).  BMSP_SEG_AVG_MAX restores a bound on the average for A/B runs.
     const char *sme = getenv("BMSP_SEG_AVG_MAX");
-    const uint64_t seg_avg_max = sme ? (uint64_t)atoll(sme) : 2048;
+    const uint64_t seg_avg_max = sme ? (uint64_t)atoll(sme) : ~0ull;
     const bool try_segmented = mode == BMSP_SORT_SEGMENTED ||
                                (mode == BMSP_SORT_AUTO && avg_seg >= 4 && (avg_seg <= seg_avg_max || (seg_bound > 0 && seg_bound <= 16384)));
     S->sort_path = 0;
