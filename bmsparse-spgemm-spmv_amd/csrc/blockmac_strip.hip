@@ -636,9 +636,14 @@ bool mac_strip_eligible(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, ui
     return mac_strip_fits_c(C, st) && mac_strip_operands_ok(A, B, st);
 }
 
-void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st)
+int launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st)
 {
     const bool f32 = A->dtype == BMSP_F32;
+    // fp32 operands of nearly empty tiles: only the scalar products that exist (blockmac_rowsparse.hip; same numerics, same preconditions)
+    if (f32 && !getenv("BMSP_STRIP_PROF") && mac_rowsparse_applies(A, B)) {
+        launch_mac_rowsparse(A, B, C, st);
+        return BMSP_MAC_ROWSPARSE;
+    }
     if (f32) { ensure_lane_tiles(A, st); ensure_lane_tiles(B, st); }
     else { ensure_dense_tiles(A, st); ensure_dense_tiles(B, st); }
     ensure_rowptr(A, st);
@@ -673,12 +678,13 @@ void launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipS
         const double w = (double)(h[5] ? h[5] : 1);
         fprintf(stderr, "strip prof (ticks per wave, %llu waves): set-up %.0f  scans %.0f  requests+lines+mfma %.0f (of which waiting for lines, fp32 build: %.0f)  stores %.0f  whole %.0f\n", h[5], h[0] / w,
                 h[1] / w, h[2] / w, h[6] / w, h[3] / w, h[4] / w);
-        return;
+        return BMSP_MAC_STRIP;
     }
     if (f32) hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3, true>), grid, dim3(kThreads), 0, st, g);
     else if (getenv("BMSP_STRIP_WIDE")) hipLaunchKernelGGL((block_mac_strip_kernel<16, 16, 2>), grid, dim3(kThreads), 0, st, g);  // experiment switch
     else hipLaunchKernelGGL((block_mac_strip_kernel<16, 8, 3>), grid, dim3(kThreads), 0, st, g);
     BMSP_CHECK_LAUNCH();
+    return BMSP_MAC_STRIP;
 }
 
 }  // namespace bmsp

@@ -174,6 +174,7 @@ bool pool_owns(void *p)
 void warm_blockmac32(hipStream_t st);
 void warm_blockmac_f32(hipStream_t st);
 void warm_blockmac_strip(hipStream_t st);
+void warm_blockmac_rowsparse(hipStream_t st);
 void warm_builder(hipStream_t st);
 void warm_rowmerge(hipStream_t st);
 void warm_rowwindow(hipStream_t st);
@@ -201,6 +202,7 @@ void load_kernels()
     warm_blockmac32(nullptr);
     warm_blockmac_f32(nullptr);
     warm_blockmac_strip(nullptr);
+    warm_blockmac_rowsparse(nullptr);
     warm_builder(nullptr);
     warm_rowmerge(nullptr);
     warm_rowwindow(nullptr);

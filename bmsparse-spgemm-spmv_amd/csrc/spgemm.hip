@@ -930,8 +930,7 @@ static void launch_block_mac(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *
         if (tc_version == 4 && !old_mac && mac_mfma32_supported(A, B)) {
             // many tasks per C tile and most candidate pairs alive: the strip kernel (operand reuse; reads A, B, C, not the task list)
             if (mac_strip_eligible(A, B, C, total, n_tasks, st)) {
-                launch_mac_strip(A, B, C, st);
-                S->mac_variant = BMSP_MAC_STRIP;
+                S->mac_variant = launch_mac_strip(A, B, C, st);
             } else {
                 S->mac_variant = launch_mac_mfma32(tasks_sorted, n_tasks, task_begin, c_of_wave, A, B, C, st);
             }
@@ -1099,8 +1098,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
             finish_structure();
             tm.mark(9);
             if (C->block_num && !structure_only) {
-                launch_mac_strip(A, B, C.get(), st);
-                S->mac_variant = BMSP_MAC_STRIP;
+                S->mac_variant = launch_mac_strip(A, B, C.get(), st);
                 S->mac_kernel = mfma ? tc_version : 5;
             } else if (C->nnz) {
                 BMSP_HIP(hipMemsetAsync(C->values, 0, dtype_size(C->dtype) * (size_t)C->nnz, st));  // bmsp_spgemm_symbolic: structure only
@@ -1344,11 +1342,11 @@ void spgemm_numeric(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc
     if (stamped && C->block_num && strip_numeric && !(sf && sf[0] == '0') && mac_strip_operands_ok(A, B, st) && mac_strip_fits_c(C, st)) {
         StageTimer tm(st, true);
         tm.mark(-1);
-        launch_mac_strip(A, B, C, st);
+        const int variant = launch_mac_strip(A, B, C, st);
         tm.mark(7);
         BMSP_HIP(hipStreamSynchronize(st));
         S->t_us[0] = tm.collect(S->t_us);
-        S->mac_variant = BMSP_MAC_STRIP;
+        S->mac_variant = variant;
         S->mac_kernel = mfma ? tc_version : 5;
         S->c_blocks = C->block_num; S->c_nnz = C->nnz;
         return;

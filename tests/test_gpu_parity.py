@@ -468,7 +468,8 @@ def test_fp32_mfma_cancellation_corner(oracle, bmsp):
     vb = ((1.0 + (np.arange(r.size) % 5) * 2.0 ** -22) * 2.0 ** -63).astype(np.float32).astype(np.float64)
     st = check_spgemm(oracle, bmsp, (n, n, r, c, va), (n, n, r, c, vb), 0, 0, 5, exact_expected=True)
     assert st["sort_path"] == 2, st
-    assert (st["mac_variant"] == 3) == (floor.value == 128), (st, floor.value)   # exponents sum to ~2 * 127 - 123 = 131: above 128, below 174
+    assert (st["mac_variant"] in (3, 5)) == (floor.value == 128), (st, floor.value)   # exponents sum to ~2 * 127 - 123 = 131: above 128, below 174
+    # (3: the matrix-core strip kernel, 5: the row-sparse kernel -- V15's chain over the stored products only; both need normal products)
 
 
 def test_tile_product_byte_permute_form(bmsp):
@@ -645,6 +646,42 @@ def test_spgemm_long_segments_radix_by_default(bmsp, monkeypatch, scale, ef):
         np.testing.assert_array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8))
 
 
+@pytest.mark.parametrize("case", ["fem", "banded64", "banded_wide", "rect_ragged", "filtered_run", "empty_strips", "long_b_rows", "cancel"])
+def test_spgemm_rowsparse_block_mac(oracle, bmsp, monkeypatch, case):
+    """block_mac_rowsparse_kernel forced on fp32 operands of every fill (BMSP_MAC_ROWSPARSE=1): V15's fmaf chain over the products of
+    STORED values only, accumulators per C value in LDS -- the values must be the oracle's bit for bit.  `fem`: nearly empty tiles (what
+    the launcher picks the kernel for); `banded64` / `banded_wide`: full tiles -- a step's 64 tiles hold 4096 values, eight times what is
+    parked in LDS (the rest is read from memory), and a block-row of C holds up to 8 K values, four accumulator windows, each a walk of
+    its own; `long_b_rows`: block-rows of B of 150 tiles, three steps per A tile, the value run of the later steps found by scalar loads;
+    `cancel`: sums that end in +0 after exact cancellation, beside tiles of unequal task counts."""
+    from pybmsp import gen
+    if case == "long_b_rows":
+        rng = np.random.default_rng(5)
+        ra = rng.integers(0, 40, 300); ca = rng.integers(0, 32, 300)
+        rb = rng.integers(0, 32, 6000); cb = rng.integers(0, 8 * 150, 6000)
+        A = (40, 32, ra, ca, rng.standard_normal(300))
+        Bc = (32, 8 * 150, rb, cb, rng.standard_normal(6000))
+        ka = ra.astype(np.int64) * 32 + ca; kb = rb.astype(np.int64) * 1200 + cb
+        _, ia = np.unique(ka, return_index=True); _, ib = np.unique(kb, return_index=True)
+        A = (40, 32, ra[ia], ca[ia], A[4][ia]); Bc = (32, 8 * 150, rb[ib], cb[ib], Bc[4][ib])
+    elif case == "cancel":
+        # rows of A = (x, -x, y) against columns of B = (1, 1, 0): the first two products cancel exactly, some sums end in +0
+        n = 64
+        r = np.repeat(np.arange(n), 3); c = (np.repeat(np.arange(n), 3) + np.tile([0, 1, 9], n)) % n
+        va = np.tile([1.5, -1.5, 0.25], n) * (1 + np.repeat(np.arange(n), 3) % 3)
+        rb = np.repeat(np.arange(n), 2); cb = (np.repeat(np.arange(n), 2) * 0 + np.tile([3, 17], n) + np.repeat(np.arange(n), 2) // 8 * 8) % n
+        kb = rb * n + cb; _, ib = np.unique(kb, return_index=True)
+        A, Bc = (n, n, r, c, va), (n, n, rb[ib], cb[ib], np.ones(ib.size))
+    else:
+        A, Bc, _ = _strip_case(gen, oracle, case)
+        if Bc is None:
+            Bc = A
+    monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "1")
+    monkeypatch.setenv("BMSP_MAC_ROWSPARSE", "1")
+    st = check_spgemm(oracle, bmsp, A, Bc, 0, 0, 5)
+    assert st["sort_path"] == 2 and (st["c_blocks"] == 0 or (st["mac_variant"] == 5 and st["mac_kernel"] == 5)), st
+
+
 def test_mfma_f32_accumulation_order(bmsp):
     """v_mfma_f32_16x16x4_f32 accumulates its four k as the ascending fmaf chain (checked on the hardware against a host fmaf chain on
     random operands of mixed magnitude): the property the fp32 matrix-core block-MAC (BMSP_MAC_F32MFMA) rests on."""
@@ -815,7 +852,15 @@ def test_spgemm_rowmerge_path(oracle, bmsp, monkeypatch, case, dtype):
     if case == "rmat_hub":
         assert st["sort_path"] == 3, st  # round 4: hub block-rows take the column-window passes (rowwindow.hip), not the pipeline
         return
-    assert st["sort_path"] == 2 and (st["c_blocks"] == 0 or (st["mac_variant"] == 3 and st["mac_kernel"] == tc)), st
+    # fp32: the strip kernel on the matrix cores (3) or, for nearly empty tiles, the row-sparse kernel (5); each is also run where the
+    # launcher would have taken the other
+    assert st["sort_path"] == 2 and (st["c_blocks"] == 0 or (st["mac_variant"] in ((3, 5) if dtype == 0 else (3,)) and st["mac_kernel"] == tc)), st
+    if dtype == 0:
+        for forced, variant in (("1", 5), ("0", 3)):
+            monkeypatch.setenv("BMSP_MAC_ROWSPARSE", forced)
+            stf = check_spgemm(oracle, bmsp, A, Bc, dtype, 0, tc, exact_expected=exact)
+            assert stf["sort_path"] == 2 and (stf["c_blocks"] == 0 or stf["mac_variant"] == variant), stf
+        monkeypatch.delenv("BMSP_MAC_ROWSPARSE")
     a = bmsp.BmSpMatrix.from_coo(*A, dtype=dtype)
     b = bmsp.BmSpMatrix.from_coo(*Bc, transposed=True, dtype=dtype)
     new, _ = bmsp.spgemm(a, b, tc_version=tc)
@@ -974,9 +1019,9 @@ def test_spgemm_fp32_exponent_range_keeps_v15(oracle, bmsp, scale):
     st = check_spgemm(oracle, bmsp, A, A, 0, 0, 5, exact_expected=True)
     assert st["sort_path"] == 2, st
     if scale in (3e-23, 1e19):
-        assert st["mac_variant"] != 3, st   # products underflow / may overflow: not the matrix pipe
+        assert st["mac_variant"] not in (3, 5), st   # products underflow / may overflow: neither the matrix pipe nor the chain without its zero terms
     elif scale == 1.0:
-        assert st["mac_variant"] == 3, st
+        assert st["mac_variant"] in (3, 5), st
 
 
 @pytest.mark.parametrize("case,dtype,tc", [("fem", 0, 5), ("fem", 1, 4), ("banded64", 1, 4), ("rect_ragged", 0, 5), ("fem", 2, 5), ("fem", 1, 5),
@@ -1005,7 +1050,7 @@ def test_spgemm_symbolic_numeric_split(oracle, bmsp, case, dtype, tc):
     stn = bmsp.spgemm_numeric(a, b, sym, tc_version=tc)
     np.testing.assert_array_equal(sym.host_arrays()[3], vf)
     if (dtype == 0 or (dtype == 1 and tc == 4)) and case != "rmat_hub":
-        assert stn["mac_variant"] == 3, stn  # the strip kernel alone
+        assert stn["mac_variant"] in ((3, 5) if dtype == 0 else (3,)), stn  # the strip (or, fp32 with nearly empty tiles, the row-sparse) kernel alone
     assert stn["t_us"][3] == 0 and stn["t_us"][4] == 0 and stn["t_us"][5] == 0 and stn["t_us"][7] > 0, stn  # no symbolic stage ran: T_7 from C's kept task list
     # new values, same structure
     A2 = A[:4] + (np.asarray(A[4]) * 0.5,)
