@@ -33,27 +33,41 @@ constexpr uint32_t kRsAcc = 2048;     // accumulators per window
 constexpr uint32_t kRsEmpty = 0xffffffffu;
 
 struct RsArgs {
-    const uint32_t *a_rowptr, *a_cols;  // A row-major: CSR row pointer (num_rows + 1), column of every value
-    const float *a_vals;
-    const uint32_t *b_rowptr, *b_cols;
-    const float *b_vals;
-    uint32_t a_rows, b_rows;
+    const uint32_t *a_rowptr;  // A row-major: CSR row pointer (num_rows + 1)
+    const uint32_t *a_ent;     // ... and its entries {column, value bits}
+    const uint32_t *b_rowptr, *b_ent;
+    uint32_t a_rows, b_rows, a_ent_bytes, b_ent_bytes;
     const uint64_t *c_keys, *c_bmps, *c_offs;
     const uint32_t *c_rowptr;  // per block-row
     float *c_vals;
     uint32_t block_rows;
 };
 
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+// an entry {column, value bits} as a FLOAT vector: __builtin_bit_cast(float, v[1]) of an integer vector's element reads element 0 with this
+// compiler (ROCm 7.2) -- element 1 is read as the float it is, element 0 is cast to the column
+__device__ __forceinline__ f32x2s rs_entry(rsrc_t r, uint32_t byte_off) { return __builtin_bit_cast(f32x2s, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0)); }
 struct alignas(16) RsLds {
-    uint32_t hk[kRsHash];        // block column of a C tile of the block-row; kRsEmpty = free
-    uint16_t cr[kRsHash];        // ... its index inside the block-row
-    uint64_t cb[kRsRowCap];      // C's bitmaps
-    uint32_t co[kRsRowCap + 1];  // first value of every C tile relative to the block-row's first
+    u32x4s slot[kRsHash];        // {block column of a C tile of the block-row (kRsEmpty = free), its first value relative to the block-row's
+                                 // first, its bitmap (lo, hi)}: ONE 16-byte read per probe gives all a product needs
+    uint32_t co[kRsRowCap + 1];  // first value of every C tile relative to the block-row's first, in tile order (the windows' bounds)
     float acc[kRsAcc];
-};  // 14 KB: eleven one-wave workgroups per CU
+};  // 17 KB: nine one-wave workgroups per CU
 
 __device__ __forceinline__ uint32_t rs_hash(uint32_t j) { return (j * 0x9E3779B1u) >> (32 - kRsHashBits); }
 
+// L = lanes per row of C: the wave's 64 / L lane groups take the block-row's eight rows 64 / L at a time (rows of different index never
+// meet in a C element), a group's L lanes = L entries of B's row k.  (The kernel is bound by its instruction count -- 1.4 M iterations of
+// ~110 vector instructions on the FEM-like product, where a 16-byte table slot instead of four dependent LDS reads and requests three
+// entries ahead instead of one changed nothing (407 -> 410 us) -- so L follows B's average row length, the bitmap arithmetic is
+// 32-bit (the row is uniform per group), and an entry is one 8-byte buffer load.)
+// HALF: fp16 operands with V15's numerics (tc_version 5, the reference's default configuration): the product is rounded to fp16 before
+// the fp32 add (:269-273, `__half * __half`); the entries hold the fp16 values widened to fp32 (exact), their fp32 product is exact (11 x
+// 11 bits), so one conversion to fp16 is that rounding.  No exponent condition there: an fp32 sum of fp16 values never underflows, and
+// +0 + -0 = +0, so a sum is never -0 and a left-out zero term never shows.
+template <int L, bool HALF>
 __global__ __launch_bounds__(64) void block_mac_rowsparse_kernel(RsArgs g)
 {
     __shared__ RsLds S;
@@ -67,22 +81,26 @@ __global__ __launch_bounds__(64) void block_mac_rowsparse_kernel(RsArgs g)
     if (brow >= g.block_rows) return;
     const uint32_t c0 = g.c_rowptr[brow], m = g.c_rowptr[brow + 1] - c0;
     if (m == 0 || m > kRsRowCap) return;  // (the launcher admits no product with a longer block-row of C)
-    // ---- C's block-row: column table, bitmaps, value offsets ----
-    for (uint32_t s = (uint32_t)lane; s < (uint32_t)kRsHash; s += 64) S.hk[s] = kRsEmpty;
+    // ---- C's block-row: column table (column, value offset, bitmap per slot), value offsets in tile order ----
+    for (uint32_t s = (uint32_t)lane; s < (uint32_t)kRsHash; s += 64) S.slot[s] = u32x4s{kRsEmpty, 0u, 0u, 0u};
     __builtin_amdgcn_wave_barrier();
     const uint64_t vbase = g.c_offs[c0];
     for (uint32_t r = (uint32_t)lane; r < m; r += 64) {
         const uint32_t j = key_col(g.c_keys[c0 + r]);
+        const uint64_t bm = g.c_bmps[c0 + r];
+        const uint32_t off = (uint32_t)(g.c_offs[c0 + r] - vbase);
         uint32_t slot = rs_hash(j);
-        while (atomicCAS(&S.hk[slot], kRsEmpty, j) != kRsEmpty) slot = (slot + 1u) & (uint32_t)(kRsHash - 1);  // (the columns of a block-row are distinct)
-        S.cr[slot] = (uint16_t)r;
-        S.cb[r] = g.c_bmps[c0 + r];
-        S.co[r] = (uint32_t)(g.c_offs[c0 + r] - vbase);
+        uint32_t *const words = (uint32_t *)S.slot;
+        while (atomicCAS(&words[4u * slot], kRsEmpty, j) != kRsEmpty) slot = (slot + 1u) & (uint32_t)(kRsHash - 1);  // (the columns of a block-row are distinct)
+        words[4u * slot + 1u] = off; words[4u * slot + 2u] = (uint32_t)bm; words[4u * slot + 3u] = (uint32_t)(bm >> 32);
+        S.co[r] = off;
     }
     if (lane == 0) S.co[m] = (uint32_t)(g.c_offs[c0 + m] - vbase);
     __builtin_amdgcn_wave_barrier();
 
-    const int half = lane >> 5, l32 = lane & 31, hbase = lane & 32;
+    constexpr int GROUPS = 64 / L, PASSES = 8 / GROUPS;
+    const int grp = lane / L, ll = lane % L, gbase = lane - ll;
+    const rsrc_t ra = make_rsrc(g.a_ent, g.a_ent_bytes), rb = make_rsrc(g.b_ent, g.b_ent_bytes);
     for (uint32_t w0 = 0; w0 < m;) {
         // ---- the window: C tiles [w0, w1) with at most kRsAcc values (a tile holds at most 64) ----
         const uint32_t o0 = S.co[w0];
@@ -97,68 +115,89 @@ __global__ __launch_bounds__(64) void block_mac_rowsparse_kernel(RsArgs g)
         const uint32_t nv = S.co[w1] - o0;
         for (uint32_t e = (uint32_t)lane; e < nv; e += 64) S.acc[e] = 0.f;
         __builtin_amdgcn_wave_barrier();
-        // ---- the eight rows of the block-row, two at a time (one per half of the wave) ----
-        for (int s4 = 0; s4 < 4; s4++) {
-            const uint32_t i = (uint32_t)(2 * s4 + half);  // row inside the tiles
+#pragma unroll 1
+        for (int ps = 0; ps < PASSES; ps++) {
+            const uint32_t i = (uint32_t)(GROUPS * ps + grp);  // row inside the tiles: bits 8 i .. 8 i + 7 of a C bitmap, MSB first
             const uint32_t row = brow * 8u + i;
+            const bool top = i < 4u;                   // the row's byte lies in the bitmap's high word
+            const uint32_t sh0 = 24u - 8u * (i & 3u);  // ... at this shift
             uint32_t pa0 = 0, pa1 = 0;
             if (row < g.a_rows) { pa0 = g.a_rowptr[row]; pa1 = g.a_rowptr[row + 1]; }
-            // 32 entries of A's row per half at a time: column k, value, and the bounds of B's row k
-            for (uint32_t pbase = pa0; __any(pbase < pa1); pbase += 32) {
-                const uint32_t p = pbase + (uint32_t)l32;
-                uint32_t k_l = 0, b0_l = 0, b1_l = 0;
+            // L entries of A's row per group at a time: column k, value, and the bounds of B's row k
+            for (uint32_t pbase = pa0; __any(pbase < pa1); pbase += (uint32_t)L) {
+                const uint32_t p = pbase + (uint32_t)ll;
+                uint32_t b0_l = 0, b1_l = 0;
                 float a_l = 0.f;
                 if (p < pa1) {
-                    k_l = g.a_cols[p]; a_l = g.a_vals[p];
-                    if (k_l < g.b_rows) { b0_l = g.b_rowptr[k_l]; b1_l = g.b_rowptr[k_l + 1]; }
+                    const f32x2s ea = rs_entry(ra, p << 3);
+                    const uint32_t k = __builtin_bit_cast(uint32_t, ea[0]);
+                    a_l = ea[1];
+                    if (k < g.b_rows) { b0_l = g.b_rowptr[k]; b1_l = g.b_rowptr[k + 1]; }
                 }
-                const uint32_t nt = pbase < pa1 ? min(32u, pa1 - pbase) : 0u;  // entries of this half in the chunk
-                const uint32_t nt_max = max(nt, (uint32_t)__shfl_xor((int)nt, 32, kWave));
-                // entry t of the chunk: its row of B, 32 entries per half and iteration; the first 32 entries of entry t + 1 travel meanwhile
-                auto fetch = [&](uint32_t t, uint32_t &e0, uint32_t &e1, float &a, uint32_t &col, float &b) {
-                    const int src = hbase + (int)min(t, 31u);
-                    e0 = (uint32_t)__shfl((int)b0_l, src, kWave);
-                    e1 = (uint32_t)__shfl((int)b1_l, src, kWave);
-                    a = __shfl(a_l, src, kWave);
-                    if (t >= nt) e1 = e0;
-                    col = 0; b = 0.f;
-                    const uint32_t e = e0 + (uint32_t)l32;
-                    if (e < e1) { col = g.b_cols[e]; b = g.b_vals[e]; }
+                uint32_t nt = pbase < pa1 ? min((uint32_t)L, pa1 - pbase) : 0u;  // entries of this group in the chunk
+                uint32_t nt_max = nt;
+#pragma unroll
+                for (int d = L; d < 64; d <<= 1) nt_max = max(nt_max, (uint32_t)__shfl_xor((int)nt_max, d, kWave));
+                // entry t of the chunk: its row of B, L entries per group and iteration, requested three entries ahead
+                struct Ent {
+                    uint32_t e0, e1;
+                    f32x2s cb;  // {column bits, value} of this lane's entry of B's row
+                    float a;
                 };
-                uint32_t e0, e1, col, e0n = 0, e1n = 0, coln = 0;
-                float a, b, an = 0.f, bn = 0.f;
-                fetch(0u, e0, e1, a, col, b);
-                for (uint32_t t = 0; t < nt_max; t++) {
-                    if (t + 1 < nt_max) fetch(t + 1, e0n, e1n, an, coln, bn);
-                    for (uint32_t eb = e0; __any(eb < e1); eb += 32) {
-                        if (eb != e0) {  // a row of B beyond 32 entries: the later ones are fetched here
-                            const uint32_t e = eb + (uint32_t)l32;
-                            col = 0; b = 0.f;
-                            if (e < e1) { col = g.b_cols[e]; b = g.b_vals[e]; }
-                        }
-                        if (eb + (uint32_t)l32 < e1) {
-                            const uint32_t jb = col >> 3, j = col & 7u;
-                            uint32_t slot = rs_hash(jb);
-                            for (;;) {
-                                const uint32_t key = S.hk[slot];
-                                if (key == jb) {
-                                    const uint32_t r = (uint32_t)S.cr[slot];
-                                    if (r >= w0 && r < w1) {
-                                        const uint64_t cbm = S.cb[r];
-                                        const uint32_t pc = 8u * i + j;
-                                        if ((cbm >> (63u - pc)) & 1ull) {
-                                            const uint32_t ci = S.co[r] - o0 + (pc ? (uint32_t)__popcll(cbm >> (64u - pc)) : 0u);
-                                            S.acc[ci] = __builtin_fmaf(a, b, S.acc[ci]);
-                                        }
-                                    }
-                                    break;
+                auto fetch = [&](uint32_t t) {
+                    Ent q;
+                    const int src = gbase + (int)min(t, (uint32_t)(L - 1));
+                    q.e0 = (uint32_t)__shfl((int)b0_l, src, kWave);
+                    q.e1 = (uint32_t)__shfl((int)b1_l, src, kWave);
+                    q.a = __shfl(a_l, src, kWave);
+                    if (t >= nt) q.e1 = q.e0;
+                    const uint32_t e = q.e0 + (uint32_t)ll;
+                    q.cb = rs_entry(rb, e < q.e1 ? e << 3 : kOob);
+                    return q;
+                };
+                auto product = [&](uint32_t col, float b, float a) {
+                    const uint32_t jb = col >> 3, j = col & 7u;
+                    uint32_t slot = rs_hash(jb);
+                    for (;;) {
+                        const u32x4s sl = S.slot[slot];
+                        if (sl[0] == jb) {
+                            if (sl[1] - o0 < nv) {  // the tile lies in the window (its values start inside the window's run)
+                                const uint32_t word = top ? sl[3] : sl[2];
+                                const uint32_t shb = sh0 + 7u - j;  // bit of (i, j) inside the word
+                                if ((word >> shb) & 1u) {
+                                    const uint32_t ci = sl[1] - o0 + (top ? 0u : (uint32_t)__builtin_popcount(sl[3])) + (uint32_t)__builtin_popcount((word >> 1) >> shb);
+                                    if constexpr (HALF) S.acc[ci] = S.acc[ci] + (float)(_Float16)(a * b);
+                                    else S.acc[ci] = __builtin_fmaf(a, b, S.acc[ci]);
                                 }
-                                if (key == kRsEmpty) break;  // (cannot happen for a product of stored values: C's structure holds its tile)
-                                slot = (slot + 1u) & (uint32_t)(kRsHash - 1);
+                            }
+                            break;
+                        }
+                        if (sl[0] == kRsEmpty) break;  // (cannot happen for a product of stored values: C's structure holds its tile)
+                        slot = (slot + 1u) & (uint32_t)(kRsHash - 1);
+                    }
+                };
+                // four entries in flight, each in registers of its own (a rotating set cost fifteen moves per iteration)
+                auto step = [&](Ent &q, uint32_t t) {
+                    if (t >= nt_max) return;
+                    const Ent c = q;
+                    if (t + 4 < nt_max) q = fetch(t + 4);
+                    if (c.e0 + (uint32_t)ll < c.e1) product(__builtin_bit_cast(uint32_t, c.cb[0]), c.cb[1], c.a);
+                    if (__any(c.e0 + (uint32_t)L < c.e1)) {  // a row of B beyond L entries: the later ones are fetched here
+                        for (uint32_t eb = c.e0 + (uint32_t)L; __any(eb < c.e1); eb += (uint32_t)L) {
+                            const uint32_t e = eb + (uint32_t)ll;
+                            if (e < c.e1) {
+                                const f32x2s cb = rs_entry(rb, e << 3);
+                                product(__builtin_bit_cast(uint32_t, cb[0]), cb[1], c.a);
                             }
                         }
                     }
-                    e0 = e0n; e1 = e1n; a = an; col = coln; b = bn;
+                };
+                Ent q0 = fetch(0u), q1 = q0, q2 = q0, q3 = q0;
+                if (1u < nt_max) q1 = fetch(1u);
+                if (2u < nt_max) q2 = fetch(2u);
+                if (3u < nt_max) q3 = fetch(3u);
+                for (uint32_t t = 0; t < nt_max; t += 4) {
+                    step(q0, t); step(q1, t + 1); step(q2, t + 2); step(q3, t + 3);
                 }
             }
         }
@@ -183,45 +222,52 @@ struct RsRowPtr {  // CSR row pointer from the sorted (row << 32 | column) words
         for (uint32_t r = lo; r <= hi; r++) rowptr[r] = (uint32_t)i;
     }
 };
-struct RsColsVals {
+struct RsEntries {
     const uint64_t *rc;
     const double *dv;
-    uint32_t *cols;
-    float *vals;
-    __device__ void operator()(uint64_t i) const { cols[i] = (uint32_t)rc[i]; vals[i] = (float)dv[i]; }  // (the values were floats: exact)
+    uint32_t *ent;
+    __device__ void operator()(uint64_t i) const
+    {
+        ent[2 * i] = (uint32_t)rc[i];
+        ent[2 * i + 1] = __builtin_bit_cast(uint32_t, (float)dv[i]);  // (the values were floats: exact)
+    }
 };
 
 }  // namespace
 
-// row-major CSR copy of an fp32 matrix (row pointer, columns, values), whatever its tile layout: built once per matrix, like the dense
+// row-major CSR copy of an fp32 or fp16 matrix (row pointer, {column, value as fp32} entries), whatever its tile layout: built once per matrix, like the dense
 // tile copies; dropped by bmsp_matrix_invalidate
 void ensure_csr32(bmsp_matrix_s *m, hipStream_t st)
 {
     if (m->csr_rowptr) return;
     const uint64_t n = (uint64_t)m->nnz;
     m->csr_rowptr = (uint32_t *)pool_alloc(4 * ((size_t)m->num_rows + 1));
-    m->csr_cols = (uint32_t *)pool_alloc(4 * (size_t)(n ? n : 1));
-    m->csr_vals = (float *)pool_alloc(4 * (size_t)(n ? n : 1));
+    m->csr_ent = (uint32_t *)pool_alloc(8 * (size_t)(n ? n : 1));
     DevBuf<uint64_t> rc(n ? n : 1);
     DevBuf<double> dv(n ? n : 1);
     matrix_to_coo_device(m, rc.p, dv.p, st);
     device_for_each(RsRowPtr{rc.p, n, (uint32_t)m->num_rows, m->csr_rowptr}, n + 1, st);
-    if (n) device_for_each(RsColsVals{rc.p, dv.p, m->csr_cols, m->csr_vals}, n, st);
+    if (n) device_for_each(RsEntries{rc.p, dv.p, m->csr_ent}, n, st);
     BMSP_HIP(hipStreamSynchronize(st));  // rc / dv go back to the pool
 }
 
-// fp32 operands of nearly empty tiles (at most 16 stored values per tile on average on both sides): the scalar products that exist are
-// a few per cent of what the matrix-core kernel multiplies.  The caller has established mac_strip_operands_ok (finite values, every
-// product a normal number) and a block-row of C of at most mac_strip_row_cap() tiles.  BMSP_MAC_ROWSPARSE=0/1: never / whatever the fill.
-bool mac_rowsparse_applies(bmsp_matrix_s *A, bmsp_matrix_s *B)
+// Operands of nearly empty tiles (at most 16 stored values per tile on average on both sides) whose product takes V15's numerics -- fp32
+// operands under any tc_version, fp16 operands under tc_version 5: the scalar products that exist are a few per cent of what a
+// tile-by-tile kernel multiplies.  Needs finite values and, for fp32, every product of stored values a normal number (biased exponents
+// summing to >= 128); the caller bounds the block-rows of C by mac_strip_row_cap() tiles.  BMSP_MAC_ROWSPARSE=0/1: never / whatever
+// the fill.
+bool mac_rowsparse_applies(bmsp_matrix_s *A, bmsp_matrix_s *B, int tc_version, hipStream_t st)
 {
     const char *e = getenv("BMSP_MAC_ROWSPARSE");
     if (e && e[0] == '0') return false;
-    if (A->dtype != BMSP_F32 || B->dtype != BMSP_F32) return false;
-    if ((uint64_t)A->nnz >= (1ull << 32) || (uint64_t)B->nnz >= (1ull << 32)) return false;
+    if (A->dtype != B->dtype || (A->dtype != BMSP_F32 && !(A->dtype == BMSP_F16 && tc_version == 5))) return false;
+    if ((uint64_t)A->nnz >= (1ull << 29) || (uint64_t)B->nnz >= (1ull << 29)) return false;  // (8-byte entries behind 32-bit byte offsets)
     if (A->view_values_end || B->view_values_end || A->ownership == 2 || B->ownership == 2) return false;  // (row-panel views: no copy of their own)
-    if (e && e[0] == '1') return true;
-    return A->nnz <= 16 * A->block_num && B->nnz <= 16 * B->block_num;
+    if (!(e && e[0] == '1') && !(A->nnz <= 16 * A->block_num && B->nnz <= 16 * B->block_num)) return false;
+    ensure_finite_flag(A, st);
+    ensure_finite_flag(B, st);
+    if (A->values_finite != 1 || B->values_finite != 1) return false;
+    return A->dtype != BMSP_F32 || A->f32_exp_min + B->f32_exp_min >= 128;
 }
 
 void launch_mac_rowsparse(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st)
@@ -230,11 +276,19 @@ void launch_mac_rowsparse(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, 
     ensure_csr32(B, st);
     ensure_rowptr(C, st);
     RsArgs g{};
-    g.a_rowptr = A->csr_rowptr; g.a_cols = A->csr_cols; g.a_vals = A->csr_vals; g.a_rows = (uint32_t)A->num_rows;
-    g.b_rowptr = B->csr_rowptr; g.b_cols = B->csr_cols; g.b_vals = B->csr_vals; g.b_rows = (uint32_t)B->num_rows;
+    g.a_rowptr = A->csr_rowptr; g.a_ent = A->csr_ent; g.a_rows = (uint32_t)A->num_rows; g.a_ent_bytes = (uint32_t)((uint64_t)A->nnz * 8u);
+    g.b_rowptr = B->csr_rowptr; g.b_ent = B->csr_ent; g.b_rows = (uint32_t)B->num_rows; g.b_ent_bytes = (uint32_t)((uint64_t)B->nnz * 8u);
     g.c_keys = C->keys; g.c_bmps = C->bmps; g.c_offs = C->offsets; g.c_rowptr = C->rowptr; g.c_vals = (float *)C->values;
     g.block_rows = (uint32_t)A->num_block_rows();
-    hipLaunchKernelGGL(block_mac_rowsparse_kernel, dim3(g.block_rows), dim3(64), 0, st, g);
+    // lanes per row of C from B's average row length (a group's lanes = the entries of one row of B); BMSP_RS_LANES = 8 / 16 / 32 for A/B runs
+    const uint64_t avg = B->num_rows ? (uint64_t)B->nnz / (uint64_t)B->num_rows : 0;
+    int lanes = avg <= 10 ? 8 : (avg <= 20 ? 16 : 32);
+    if (const char *e = getenv("BMSP_RS_LANES")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) lanes = v; }
+    const dim3 grid(g.block_rows), block(64);
+    const bool half = A->dtype == BMSP_F16;
+    if (lanes == 8) { if (half) hipLaunchKernelGGL((block_mac_rowsparse_kernel<8, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((block_mac_rowsparse_kernel<8, false>), grid, block, 0, st, g); }
+    else if (lanes == 16) { if (half) hipLaunchKernelGGL((block_mac_rowsparse_kernel<16, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((block_mac_rowsparse_kernel<16, false>), grid, block, 0, st, g); }
+    else { if (half) hipLaunchKernelGGL((block_mac_rowsparse_kernel<32, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((block_mac_rowsparse_kernel<32, false>), grid, block, 0, st, g); }
     BMSP_CHECK_LAUNCH();
 }
 

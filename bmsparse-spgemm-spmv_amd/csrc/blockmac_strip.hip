@@ -636,11 +636,19 @@ bool mac_strip_eligible(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, ui
     return mac_strip_fits_c(C, st) && mac_strip_operands_ok(A, B, st);
 }
 
-int launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st)
+// the numeric stages that need no task list: the row-sparse kernel (V15 numerics on nearly empty tiles) or the strip kernels
+bool mac_structure_numeric_ok(bmsp_matrix_s *A, bmsp_matrix_s *B, int tc_version, hipStream_t st)
+{
+    if (mac_rowsparse_applies(A, B, tc_version, st)) return true;
+    if (A->dtype == BMSP_F16 && tc_version != 4) return false;  // the fp16 strip kernel has the matrix cores' numerics
+    return mac_strip_operands_ok(A, B, st);
+}
+
+int launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc_version, hipStream_t st)
 {
     const bool f32 = A->dtype == BMSP_F32;
-    // fp32 operands of nearly empty tiles: only the scalar products that exist (blockmac_rowsparse.hip; same numerics, same preconditions)
-    if (f32 && !getenv("BMSP_STRIP_PROF") && mac_rowsparse_applies(A, B)) {
+    // V15 numerics on nearly empty tiles: only the scalar products that exist (blockmac_rowsparse.hip)
+    if (!getenv("BMSP_STRIP_PROF") && mac_rowsparse_applies(A, B, tc_version, st)) {
         launch_mac_rowsparse(A, B, C, st);
         return BMSP_MAC_ROWSPARSE;
     }

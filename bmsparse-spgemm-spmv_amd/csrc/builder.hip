@@ -380,7 +380,7 @@ void free_matrix(bmsp_matrix_s *m)
     pool_free(m->col_index); pool_free(m->col_index_row); pool_free(m->col_mass);
     pool_free(m->dense_tiles);
     pool_free(m->lane_tiles);
-    pool_free(m->csr_rowptr); pool_free(m->csr_cols); pool_free(m->csr_vals);
+    pool_free(m->csr_rowptr); pool_free(m->csr_ent);
     pool_free(m->sp_tasks); pool_free(m->sp_task_begin); pool_free(m->sp_c_of_wave);
     free_matrix(m->shard_view);
     delete m;
@@ -395,8 +395,8 @@ void invalidate_matrix(bmsp_matrix_s *m, int structure_changed)
     BMSP_HIP(hipDeviceSynchronize());  // no kernel may still be reading what is about to go back to the pool
     pool_free(m->dense_tiles); m->dense_tiles = nullptr;
     pool_free(m->lane_tiles); m->lane_tiles = nullptr;
-    pool_free(m->csr_rowptr); pool_free(m->csr_cols); pool_free(m->csr_vals);
-    m->csr_rowptr = nullptr; m->csr_cols = nullptr; m->csr_vals = nullptr;
+    pool_free(m->csr_rowptr); pool_free(m->csr_ent);
+    m->csr_rowptr = nullptr; m->csr_ent = nullptr;
     m->values_finite = -1;
     if (!structure_changed) return;
     pool_free(m->rowptr); m->rowptr = nullptr; m->rowptr_rows = 0; m->max_row_blocks = -1;

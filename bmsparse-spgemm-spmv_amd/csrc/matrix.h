@@ -49,8 +49,7 @@ struct bmsp_matrix_s {
     int col_index_tried = 0;
     // fp16 matrices: every tile expanded to 64 halves in position order (128 B per block), for the K = 32 MFMA block-MAC: built lazily
     void *dense_tiles = nullptr;
-    uint32_t *csr_rowptr = nullptr, *csr_cols = nullptr;  // fp32 operands of the row-sparse block-MAC: a row-major CSR copy (num_rows + 1 / nnz / nnz entries)
-    float *csr_vals = nullptr;
+    uint32_t *csr_rowptr = nullptr, *csr_ent = nullptr;  // fp32 operands of the row-sparse block-MAC: a row-major CSR copy (row pointer of num_rows + 1 entries; {column, value bits} per stored value)
     void *lane_tiles = nullptr;   // fp32 matrices: tiles in the lane order of the fp32 MFMA block-MAC (256 B per block): built lazily
     // SpGEMM row-merge paths: the right operand (keys pointer, block count) this matrix was last multiplied with and what that product
     // turned out to need (1 strip mode, 2 task-list mode, 3 the pipeline, 4 column windows) -- the next product of the pair goes there directly
@@ -152,9 +151,10 @@ bool mac_strip_eligible(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, ui
 bool mac_strip_operands_ok(bmsp_matrix_s *A, bmsp_matrix_s *B, hipStream_t st);
 bool mac_strip_fits_c(bmsp_matrix_s *C, hipStream_t st);
 uint32_t mac_strip_row_cap();
-int launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);  // returns the BMSP_MAC_* variant that ran (strip, or row-sparse for fp32 operands of nearly empty tiles)
+int launch_mac_strip(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc_version, hipStream_t st);  // returns the BMSP_MAC_* variant that ran (strip, or row-sparse for V15 numerics on nearly empty tiles)
+bool mac_structure_numeric_ok(bmsp_matrix_s *A, bmsp_matrix_s *B, int tc_version, hipStream_t st);  // a numeric stage that works from C's structure alone exists for these operands
 void ensure_csr32(bmsp_matrix_s *m, hipStream_t st);
-bool mac_rowsparse_applies(bmsp_matrix_s *A, bmsp_matrix_s *B);
+bool mac_rowsparse_applies(bmsp_matrix_s *A, bmsp_matrix_s *B, int tc_version, hipStream_t st);
 void launch_mac_rowsparse(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);
 bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, uint32_t row_cap,
                        uint64_t *surviving, uint64_t *candidates, hipStream_t st);

@@ -930,7 +930,7 @@ static void launch_block_mac(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *
         if (tc_version == 4 && !old_mac && mac_mfma32_supported(A, B)) {
             // many tasks per C tile and most candidate pairs alive: the strip kernel (operand reuse; reads A, B, C, not the task list)
             if (mac_strip_eligible(A, B, C, total, n_tasks, st)) {
-                S->mac_variant = launch_mac_strip(A, B, C, st);
+                S->mac_variant = launch_mac_strip(A, B, C, tc_version, st);
             } else {
                 S->mac_variant = launch_mac_mfma32(tasks_sorted, n_tasks, task_begin, c_of_wave, A, B, C, st);
             }
@@ -1081,7 +1081,10 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         };
         // numeric stages that work from C's structure alone: the K = 32 MFMA strip kernel (tc_version 4, fp16) and its fp32 form (V15's
         // summation order on v_mfma_f32_16x16x4_f32: any tc_version, as fp32 operands always take V15's numerics)
-        const bool rm_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || (A->dtype == BMSP_F32 && !getenv("BMSP_MAC_VALU_DENSE") && !getenv("BMSP_MAC_F32MFMA"));
+        // ... and the row-sparse kernel: V15 numerics (fp32 operands, or fp16 under tc_version 5 -- the reference's default configuration) on
+        // operands of nearly empty tiles
+        const bool rm_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || (A->dtype == BMSP_F32 && !getenv("BMSP_MAC_VALU_DENSE") && !getenv("BMSP_MAC_F32MFMA")) ||
+                                (A->dtype == BMSP_F16 && tc_version == 5 && !getenv("BMSP_MAC_VALU_DENSE") && mac_rowsparse_applies(A, B, tc_version, st));
         const char *sf = getenv("BMSP_MAC_STRIP");
         // BMSP_SPGEMM_ROWWINDOW=0: never the column-window passes (rowwindow.hip); =1: always, whatever the operands look like (tests)
         const char *we = getenv("BMSP_SPGEMM_ROWWINDOW");
@@ -1098,7 +1101,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
             finish_structure();
             tm.mark(9);
             if (C->block_num && !structure_only) {
-                S->mac_variant = launch_mac_strip(A, B, C.get(), st);
+                S->mac_variant = launch_mac_strip(A, B, C.get(), tc_version, st);
                 S->mac_kernel = mfma ? tc_version : 5;
             } else if (C->nnz) {
                 BMSP_HIP(hipMemsetAsync(C->values, 0, dtype_size(C->dtype) * (size_t)C->nnz, st));  // bmsp_spgemm_symbolic: structure only
@@ -1119,7 +1122,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
                                  (uint64_t)A->max_row_blocks * (uint64_t)B->max_row_blocks <= (uint64_t)mac_strip_row_cap();
         if (((known && hint == 1) || (hint == 0 && surely_fits)) && n_a && strip_allowed && (mode == BMSP_SORT_AUTO || rm_force) && !rm_off &&
             (uint64_t)A->num_block_rows() * (uint64_t)mac_strip_row_cap() * 12 <= (4ull << 30) &&  // (beyond: T_2 first, scratch sized by the candidate pairs)
-            mac_strip_operands_ok(A, B, st)) {
+            mac_structure_numeric_ok(A, B, tc_version, st)) {
             uint64_t surv = 0;
             strip_tried = true;
             if (rowmerge_symbolic(A, B, C.get(), nullptr, 0, mac_strip_row_cap(), &surv, &total, st)) {
@@ -1134,7 +1137,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
         run_t2();
         const bool rm_on = !rm_off && total && (mode == BMSP_SORT_AUTO || rm_force);
         bool try_strip = rm_on && strip_allowed && !strip_tried && hint != 2 && hint != 3 && hint != 4;
-        if (try_strip) try_strip = mac_strip_operands_ok(A, B, st);
+        if (try_strip) try_strip = mac_structure_numeric_ok(A, B, tc_version, st);
         if (try_strip) {
             uint64_t surv = 0, cand = 0;
             if (rowmerge_symbolic(A, B, C.get(), first_pos.p, total, mac_strip_row_cap(), &surv, &cand, st)) {
@@ -1331,7 +1334,7 @@ void spgemm_numeric(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc
     bmsp_spgemm_stats *S = stats ? stats : &local;
     *S = bmsp_spgemm_stats{};
     const bool mfma = tc_version != 5 && A->dtype == BMSP_F16;
-    const bool strip_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || A->dtype == BMSP_F32;
+    const bool strip_numeric = (tc_version == 4 && mfma && !getenv("BMSP_MAC_OLD")) || A->dtype == BMSP_F32 || (A->dtype == BMSP_F16 && tc_version == 5);
     const char *sf = getenv("BMSP_MAC_STRIP");
     // The kernels below write C's values from the operands' structure and trust C to hold the product's: they run only for a C stamped
     // with THESE operands' fingerprints (a product of bmsp_spgemm / _symbolic on operands of the same structure).  A stamped C of other
@@ -1339,10 +1342,10 @@ void spgemm_numeric(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, int tc
     const bool stamped = C->sp_a_hash != 0 && C->sp_b_hash != 0;
     if (stamped && (C->sp_a_hash != ensure_struct_hash(A, st) || C->sp_b_hash != ensure_struct_hash(B, st)))
         fail(BMSP_ERR_INVALID, "C holds the structure of a product of other operands (its stamp does not match A and B)");
-    if (stamped && C->block_num && strip_numeric && !(sf && sf[0] == '0') && mac_strip_operands_ok(A, B, st) && mac_strip_fits_c(C, st)) {
+    if (stamped && C->block_num && strip_numeric && !(sf && sf[0] == '0') && mac_structure_numeric_ok(A, B, tc_version, st) && mac_strip_fits_c(C, st)) {
         StageTimer tm(st, true);
         tm.mark(-1);
-        const int variant = launch_mac_strip(A, B, C, st);
+        const int variant = launch_mac_strip(A, B, C, tc_version, st);
         tm.mark(7);
         BMSP_HIP(hipStreamSynchronize(st));
         S->t_us[0] = tm.collect(S->t_us);

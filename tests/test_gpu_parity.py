@@ -646,14 +646,17 @@ def test_spgemm_long_segments_radix_by_default(bmsp, monkeypatch, scale, ef):
         np.testing.assert_array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8))
 
 
+@pytest.mark.parametrize("lanes", ["", "8", "16", "32"])
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", ["fem", "banded64", "banded_wide", "rect_ragged", "filtered_run", "empty_strips", "long_b_rows", "cancel"])
-def test_spgemm_rowsparse_block_mac(oracle, bmsp, monkeypatch, case):
-    """block_mac_rowsparse_kernel forced on fp32 operands of every fill (BMSP_MAC_ROWSPARSE=1): V15's fmaf chain over the products of
-    STORED values only, accumulators per C value in LDS -- the values must be the oracle's bit for bit.  `fem`: nearly empty tiles (what
-    the launcher picks the kernel for); `banded64` / `banded_wide`: full tiles -- a step's 64 tiles hold 4096 values, eight times what is
-    parked in LDS (the rest is read from memory), and a block-row of C holds up to 8 K values, four accumulator windows, each a walk of
-    its own; `long_b_rows`: block-rows of B of 150 tiles, three steps per A tile, the value run of the later steps found by scalar loads;
-    `cancel`: sums that end in +0 after exact cancellation, beside tiles of unequal task counts."""
+def test_spgemm_rowsparse_block_mac(oracle, bmsp, monkeypatch, case, dtype, lanes):
+    """block_mac_rowsparse_kernel forced on operands of every fill (BMSP_MAC_ROWSPARSE=1), V15's numerics (tc_version 5) on fp32 and on fp16
+    operands (the reference's default configuration: products rounded to fp16, fp32 adds): the chain over the products of STORED values
+    only, row-wise over CSR copies, accumulators per C value in LDS -- the values must be the oracle's bit for bit, with 8, 16 or 32
+    lanes per row of C or the launcher's choice.  `fem`: nearly empty tiles (what the launcher picks the kernel for); `banded64` /
+    `banded_wide`: full tiles -- rows of B of 129 and 513 entries (several iterations per entry of A), block-rows of C of up to 8 K values
+    (four accumulator windows, each a walk of its own); `long_b_rows`: rows of B of ~190 entries against rows of A of a few;
+    `cancel`: sums that end in +0 after exact cancellation."""
     from pybmsp import gen
     if case == "long_b_rows":
         rng = np.random.default_rng(5)
@@ -678,7 +681,9 @@ def test_spgemm_rowsparse_block_mac(oracle, bmsp, monkeypatch, case):
             Bc = A
     monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "1")
     monkeypatch.setenv("BMSP_MAC_ROWSPARSE", "1")
-    st = check_spgemm(oracle, bmsp, A, Bc, 0, 0, 5)
+    if lanes:
+        monkeypatch.setenv("BMSP_RS_LANES", lanes)
+    st = check_spgemm(oracle, bmsp, A, Bc, dtype, 0, 5)
     assert st["sort_path"] == 2 and (st["c_blocks"] == 0 or (st["mac_variant"] == 5 and st["mac_kernel"] == 5)), st
 
 
@@ -1018,8 +1023,10 @@ def test_spgemm_fp32_exponent_range_keeps_v15(oracle, bmsp, scale):
     A = (n, n, r, c, vv)
     st = check_spgemm(oracle, bmsp, A, A, 0, 0, 5, exact_expected=True)
     assert st["sort_path"] == 2, st
-    if scale in (3e-23, 1e19):
-        assert st["mac_variant"] not in (3, 5), st   # products underflow / may overflow: neither the matrix pipe nor the chain without its zero terms
+    if scale == 3e-23:
+        assert st["mac_variant"] not in (3, 5), st   # products underflow: neither the matrix pipe nor the chain without its zero terms
+    elif scale == 1e19:
+        assert st["mac_variant"] != 3, st            # sums may overflow: not the matrix pipe (the row-sparse chain is the reference's own operations)
     elif scale == 1.0:
         assert st["mac_variant"] in (3, 5), st
 
