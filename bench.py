@@ -487,16 +487,20 @@ SPGEMM_CASES = [
     ("rmat16", "rmat(scale=16, edge_factor=8)+I: 1.46e8 candidate pairs, 6.4e7 tasks, 4.5 per C tile", lambda g: g.rmat(16, 8), "F16", 4, None, "spgemm_rmat16"),
     # configs[4]'s product on ONE GPU (the N = 1 value of the sharded figure): 2.3e9 candidate pairs, run in block-row panels
     ("rmat22", "rmat(scale=22, edge_factor=1)+I (configs[4] on one GPU): 2.29e9 candidate pairs, 6.9e8 tasks, 4.8e8 C tiles, 1.44 per C tile", lambda g: g.rmat(22, 1), "F16", 4, None, "spgemm_rmat22"),
+    # the reference's DEFAULT configuration (spgemm_run_batch.sh: tc_version 5 on the half-precision build): fp16 operands, V15 numerics
+    ("fem_h5", "2cubes_sphere-like fem_like(47^3 grid, poisson27pt, windowed random renumbering)", lambda g: g.fem_like(47, "27pt"), "F16", 5, "2cubes_sphere.mtx", "spgemm_fem_like_h5"),
 ]
+NO_BASELINE_TAGS = ("ceiling", "rmat16", "rmat22", "fem_h5")  # cases without a vendor / CPU leg (fem_h5: the fp32 legs of `fem` are the same product)
 MAC_VARIANT = {0: "default kernel of the tc_version", 1: "block_mac_mfma32_kernel (K = 32, LDS-staged)", 2: "block_mac_direct_kernel (K = 32, lines per task)",
-               3: "block_mac_strip_kernel (K = 32, two block-rows per wave, operand reuse)", 4: "block_mac_f32_mfma_kernel (v_mfma_f32_16x16x4_f32, V15 chain, lane-ordered tile copies)"}
+               3: "block_mac_strip_kernel (K = 32, two block-rows per wave, operand reuse)", 4: "block_mac_f32_mfma_kernel (v_mfma_f32_16x16x4_f32, V15 chain, lane-ordered tile copies)",
+               5: "block_mac_rowsparse_kernel (V15 chain over the products of STORED values only, row-wise over CSR copies, accumulators per C value in LDS)"}
 
 
 def stage_bytes(st, sort_bits):
     """compulsory bytes of the symbolic stages for THIS library's layouts (DESIGN.md section 4 states them next to SURVEY 8(d)'s figures
     for the reference's 16-byte tasks): per candidate pair / surviving task / C block.  Keyed by the stage the time is charged to."""
     cand, surv, cb = st["task_list_size"], st["surviving_tasks"], st["c_blocks"]
-    if st["sort_path"] == 2 and st.get("mac_variant") == 3:
+    if st["sort_path"] == 2 and st.get("mac_variant") in (3, 5):
         # row-merge, strip mode (rowmerge_symbolic_kernel + emit): key + bitmap of B's tile per candidate pair; C's column + bitmap to scratch
         # (12 B), read back by the emit pass, C's key + bitmap + offset written (24 B).  T_3 holds all of it (T_9 is an allocation)
         return {"T_3": 16 * cand + 48 * cb}
@@ -616,10 +620,22 @@ def bench_spgemm(B, gen, np, args):
         kernel_files = ["bmsparse-spgemm-spmv_amd/csrc/blockmac_strip.hip", "bmsparse-spgemm-spmv_amd/csrc/blockmac32.hip", "bmsparse-spgemm-spmv_amd/csrc/blockmac_f32.hip",
                         "bmsparse-spgemm-spmv_amd/csrc/mac_common.hip.h"]
         traffic, traffic_src = profile_value("r*_%s_traffic.json" % ptag, "traffic_bytes_per_launch", kernel_files)
-        roof = {"bound": "mfma" if dtype == B.F16 else "fp32 matrix / vector rate", "kernel": MAC_VARIANT.get(best.get("mac_variant", 0), "?"),
+        roof = {"bound": "mfma" if (dtype == B.F16 and tc != 5) else "fp32 matrix / vector rate", "kernel": MAC_VARIANT.get(best.get("mac_variant", 0), "?"),
                 "achieved": round(f_mac / t_mac / 1e12, 3),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(f_mac / t_mac / 1e12 / peak, 5),
                 "traffic": traffic, "traffic_source": traffic_src}
+        if best.get("mac_variant") == 5:
+            # the row-sparse kernel multiplies the stored values only: its arithmetic is 2 flop per scalar product, and what bounds it is the
+            # bookkeeping of a product (table look-up, rank in C's bitmap, one LDS read-modify-write), not the multiply-add.  Its roofline is
+            # the memory one: the bytes of its own layout -- CSR copies of A and B (8 B per value + row pointers), C's keys, bitmaps, offsets
+            # and values -- against the HBM peak; the products per second are given beside it.
+            rs_bytes = 16 * info["nnz"] + 8 * (info["num_rows"] + 1) + 24 * best["c_blocks"] + 4 * best["c_nnz"]
+            traffic, traffic_src = profile_value("r*_%s_traffic.json" % ptag, "traffic_bytes_per_launch", ["bmsparse-spgemm-spmv_amd/csrc/blockmac_rowsparse.hip"])
+            roof = {"bound": "hbm", "kernel": MAC_VARIANT[5], "achieved": round(rs_bytes / t_mac / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(rs_bytes / t_mac / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": int(rs_bytes), "scalar_products_per_s": round(P / t_mac, 0),
+                    "dense_equivalent_TFLOPs": round(f_mac / t_mac / 1e12, 2),
+                    "note": "dense_equivalent = the 1024 flop per task the tile-by-tile kernels perform, for comparison with the other entries"}
         mu, mu_src = profile_value("r*_%s_mfma.json" % ptag, "mfma_util", kernel_files)
         if mu is not None:
             roof["mfma_util"] = mu  # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), from the committed PMC pass
@@ -628,7 +644,7 @@ def bench_spgemm(B, gen, np, args):
         sb = stage_bytes(best, sort_bits)
         stage_idx = (("T_1", 1), ("T_2", 2), ("T_3", 3), ("T_4", 4), ("T_5", 5), ("T_6", 6), ("T_9", 9), ("T_7", 7))
         stage_gbs, stage_frac = stage_fracs(sb, best["t_us"], stage_idx)
-        res.append({"workload": "bmSparse SpGEMM A*A %s, %s" % ("fp16 MFMA block-MAC" if dtype == B.F16 else "fp32", name),
+        res.append({"workload": "bmSparse SpGEMM A*A %s, %s" % (("fp16 MFMA block-MAC" if tc != 5 else "fp16 operands, V15 numerics (tc_version 5: the reference's default configuration)") if dtype == B.F16 else "fp32", name),
                     "rows": info["num_rows"], "nnz": info["nnz"], "blocks": info["block_num"],
                     "values_per_tile": round(info["nnz"] / max(1, info["block_num"]), 2),
                     "tasks": best["task_list_size"], "surviving_tasks": best["surviving_tasks"], "c_blocks": best["c_blocks"],
@@ -727,7 +743,7 @@ def vendor_column(np, gen, wl, eff_bytes, args):
     if not args.skip_spgemm:
         res["spgemm"] = []
         for tag, name, mk, dtn, tc, fname, ptag in SPGEMM_CASES:
-            if tag in ("ceiling", "rmat16", "rmat22") or (args.only_spgemm and args.only_spgemm not in tag):
+            if tag in NO_BASELINE_TAGS or (args.only_spgemm and args.only_spgemm not in tag):
                 continue
             m, ptr, col, val = csr_of(mk(gen))
             note("vendor: CSR of %s built" % tag)
@@ -905,7 +921,7 @@ def cpu_baseline(wl, eff_bytes, args):
     if not args.skip_spgemm:
         out["spgemm"] = []
         for tag, name, mk, dtn, tc, fname, ptag in SPGEMM_CASES:
-            if tag in ("ceiling", "rmat16", "rmat22") or (args.only_spgemm and args.only_spgemm not in tag):
+            if tag in NO_BASELINE_TAGS or (args.only_spgemm and args.only_spgemm not in tag):
                 continue
             gn, _, gr, gc, gv = mk(gen)
             G = O.csr_from_coo(O.Coo(gn, gn, gr, gc, gv))

@@ -23,6 +23,7 @@
 // loop -- measured 1171 and 1084 us on the FEM-like product, the second with B's values parked in LDS: 96 products per step spread over
 // eleven serialized read-modify-write iterations at one lane in seven.)
 #include "mac_common.hip.h"
+#include <algorithm>
 
 namespace bmsp {
 namespace {
@@ -210,45 +211,102 @@ __global__ __launch_bounds__(64) void block_mac_rowsparse_kernel(RsArgs g)
     }
 }
 
-struct RsRowPtr {  // CSR row pointer from the sorted (row << 32 | column) words: entry r = first word of a row >= r
-    const uint64_t *rc;
-    uint64_t n;
+// ---- the CSR copy, straight from the tiles (no sort: a block-row's tiles are in column order already) --------------------------------
+// per tile: the stored values of matrix row 8 * block-row + r, r = 0 .. 7 (the byte r of the row-major bitmap), added to the rows' counts
+struct RsRowCounts {
+    const uint64_t *keys, *bmps;
+    int transposed;
     uint32_t num_rows;
-    uint32_t *rowptr;
-    __device__ void operator()(uint64_t i) const
+    uint32_t *cnt;  // num_rows + 1 entries, zeroed
+    __device__ void operator()(uint64_t b) const
     {
-        const uint32_t hi = i < n ? (uint32_t)(rc[i] >> 32) : num_rows;
-        const uint32_t lo = i ? (uint32_t)(rc[i - 1] >> 32) + 1u : 0u;
-        for (uint32_t r = lo; r <= hi; r++) rowptr[r] = (uint32_t)i;
+        const uint64_t bm = transposed ? tile_transpose(bmps[b]) : bmps[b];
+        const uint32_t r0 = key_row(keys[b]) * 8u;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t c = (uint32_t)__builtin_popcount(tile_byte(bm, r));
+            if (c && r0 + (uint32_t)r < num_rows) atomicAdd(&cnt[r0 + (uint32_t)r], c);
+        }
     }
 };
-struct RsEntries {
-    const uint64_t *rc;
-    const double *dv;
-    uint32_t *ent;
-    __device__ void operator()(uint64_t i) const
-    {
-        ent[2 * i] = (uint32_t)rc[i];
-        ent[2 * i + 1] = __builtin_bit_cast(uint32_t, (float)dv[i]);  // (the values were floats: exact)
+
+// one wave per block-row: 64 tiles at a time (lane = tile), a packed wave scan of the tiles' eight row counts gives every tile the place
+// of its values inside each of the eight rows; the lane then writes its tile's values, row by row, column ascending
+template <typename T>
+__global__ __launch_bounds__(kThreads) void rs_fill_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ bmps, const uint64_t *__restrict__ offs,
+                                                           const T *__restrict__ vals, const uint32_t *__restrict__ block_rowptr, uint32_t block_rows,
+                                                           int transposed, uint32_t num_rows, const uint32_t *__restrict__ rowptr, uint32_t *__restrict__ ent)
+{
+    const uint32_t br = blockIdx.x * 4 + (uint32_t)wave_id();
+    if (br >= block_rows) return;
+    const int lane = lane_id();
+    const uint32_t t0 = block_rowptr[br], t1 = block_rowptr[br + 1];
+    // rows 0-3 in `lo`, rows 4-7 in `hi`: four 16-bit fields each (a block-row of 2^13 tiles of 8 values per row stays below 2^16)
+    uint64_t carry_lo = 0, carry_hi = 0;
+    for (uint32_t base = t0; base < t1; base += 64) {
+        const uint32_t t = base + (uint32_t)lane;
+        uint64_t bm = 0, stored = 0;
+        if (t < t1) { stored = bmps[t]; bm = transposed ? tile_transpose(stored) : stored; }
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            lo |= (uint64_t)__builtin_popcount(tile_byte(bm, r)) << (16 * r);
+            hi |= (uint64_t)__builtin_popcount(tile_byte(bm, 4 + r)) << (16 * r);
+        }
+        const uint64_t inc_lo = wave_inclusive_sum(lo), inc_hi = wave_inclusive_sum(hi);
+        if (t < t1 && bm) {
+            const uint64_t ex_lo = carry_lo + inc_lo - lo, ex_hi = carry_hi + inc_hi - hi;
+            const uint32_t bcol8 = key_col(keys[t]) * 8u;
+            const uint64_t off = offs[t];
+#pragma unroll 1
+            for (int r = 0; r < 8; r++) {
+                const uint32_t row = br * 8u + (uint32_t)r;
+                uint32_t byte = tile_byte(bm, r);
+                if (!byte || row >= num_rows) continue;
+                uint32_t dst = rowptr[row] + (uint32_t)(((r < 4 ? ex_lo : ex_hi) >> (16 * (r & 3))) & 0xffffull);
+                while (byte) {
+                    const int c = __builtin_clz(byte) - 24;  // column inside the tile, ascending
+                    byte &= ~(0x80u >> c);
+                    const int pos = transposed ? c * 8 + r : r * 8 + c;  // where the value sits in the stored order
+                    ent[2 * (uint64_t)dst] = bcol8 + (uint32_t)c;
+                    ent[2 * (uint64_t)dst + 1] = __builtin_bit_cast(uint32_t, (float)vals[off + (uint64_t)tile_rank(stored, pos)]);  // (fp16 -> fp32: exact)
+                    dst++;
+                }
+            }
+        }
+        carry_lo += (uint64_t)__shfl((long long)inc_lo, 63, kWave);
+        carry_hi += (uint64_t)__shfl((long long)inc_hi, 63, kWave);
     }
-};
+}
 
 }  // namespace
 
-// row-major CSR copy of an fp32 or fp16 matrix (row pointer, {column, value as fp32} entries), whatever its tile layout: built once per matrix, like the dense
-// tile copies; dropped by bmsp_matrix_invalidate
+// row-major CSR copy of an fp32 or fp16 matrix (row pointer, {column, value as fp32} entries), whatever its tile layout: built once per
+// matrix, like the dense tile copies; dropped by bmsp_matrix_invalidate
 void ensure_csr32(bmsp_matrix_s *m, hipStream_t st)
 {
     if (m->csr_rowptr) return;
     const uint64_t n = (uint64_t)m->nnz;
-    m->csr_rowptr = (uint32_t *)pool_alloc(4 * ((size_t)m->num_rows + 1));
+    const uint32_t rows = (uint32_t)m->num_rows;
+    ensure_rowptr(m, st);
+    ensure_row_stats(m, st);
+    if (m->max_row_blocks >= (1 << 13)) fail(BMSP_ERR_LIMIT, "row-sparse block-MAC: a block-row of 8192 or more tiles");
+    m->csr_rowptr = (uint32_t *)pool_alloc(4 * ((size_t)rows + 1));
     m->csr_ent = (uint32_t *)pool_alloc(8 * (size_t)(n ? n : 1));
-    DevBuf<uint64_t> rc(n ? n : 1);
-    DevBuf<double> dv(n ? n : 1);
-    matrix_to_coo_device(m, rc.p, dv.p, st);
-    device_for_each(RsRowPtr{rc.p, n, (uint32_t)m->num_rows, m->csr_rowptr}, n + 1, st);
-    if (n) device_for_each(RsEntries{rc.p, dv.p, m->csr_ent}, n, st);
-    BMSP_HIP(hipStreamSynchronize(st));  // rc / dv go back to the pool
+    BMSP_HIP(hipMemsetAsync(m->csr_rowptr, 0, 4 * ((size_t)rows + 1), st));
+    if (m->block_num) device_for_each(RsRowCounts{m->keys, m->bmps, m->transposed, rows, m->csr_rowptr}, (uint64_t)m->block_num, st);
+    device_exclusive_scan<uint32_t>(PtrIn<uint32_t>{m->csr_rowptr}, PtrOut<uint32_t>{m->csr_rowptr}, (uint64_t)rows + 1, st);
+    if (m->block_num) {
+        const uint32_t nbr = (uint32_t)m->num_block_rows();
+        const dim3 grid((nbr + 3) / 4);
+        if (m->dtype == BMSP_F32)
+            hipLaunchKernelGGL((rs_fill_kernel<float>), grid, dim3(kThreads), 0, st, m->keys, m->bmps, m->offsets, (const float *)m->values, m->rowptr, nbr, m->transposed, rows,
+                               (const uint32_t *)m->csr_rowptr, m->csr_ent);
+        else
+            hipLaunchKernelGGL((rs_fill_kernel<_Float16>), grid, dim3(kThreads), 0, st, m->keys, m->bmps, m->offsets, (const _Float16 *)m->values, m->rowptr, nbr, m->transposed,
+                               rows, (const uint32_t *)m->csr_rowptr, m->csr_ent);
+        BMSP_CHECK_LAUNCH();
+    }
 }
 
 // Operands of nearly empty tiles (at most 16 stored values per tile on average on both sides) whose product takes V15's numerics -- fp32

@@ -660,8 +660,13 @@ void prepare_spgemm_operand(bmsp_matrix_s *m, hipStream_t st)
     if (m->dtype == BMSP_F16 && m->block_num < (1ll << 25) && (!m->transposed || mac_mfma32_b_dense(m))) ensure_dense_tiles(m, st);
     // V15 block-MAC (tc_version 5): fp32 operands with tiles at least a quarter full are staged from a dense copy too (256 B per block)
     if (m->dtype == BMSP_F32 && m->nnz >= 16 * m->block_num && (uint64_t)m->block_num * 256 <= (4ull << 30)) ensure_dense_tiles(m, st);
-    // fp32 strip block-MAC (row-merge path) and the opt-in fp32 MFMA task-list kernel: the tiles in MFMA lane order (256 B per block)
-    if (m->dtype == BMSP_F32 && m->block_num < (1ll << 24) && mac_f32_mfma_usable(st)) ensure_lane_tiles(m, st);
+    // fp32 operands of nearly empty tiles: the row-sparse block-MAC's CSR copy (8 B per value) -- what such a matrix is multiplied from;
+    // otherwise the fp32 strip block-MAC's (and the opt-in fp32 MFMA task-list kernel's) tiles in MFMA lane order (256 B per block).
+    // (fp16 operands take the row-sparse kernel only under tc_version 5: their copy is made by the first such product)
+    const char *rse = getenv("BMSP_MAC_ROWSPARSE");
+    const bool sparse_tiles = m->nnz <= 16 * m->block_num && (uint64_t)m->nnz < (1ull << 29) && !m->view_values_end && m->ownership != 2 && !(rse && rse[0] == '0');
+    if (m->dtype == BMSP_F32 && sparse_tiles) ensure_csr32(m, st);
+    else if (m->dtype == BMSP_F32 && m->block_num < (1ll << 24) && mac_f32_mfma_usable(st)) ensure_lane_tiles(m, st);
     // what decides whether a product takes the row-merge path: block-row pointer and maxima, "every stored value is finite"
     ensure_row_stats(m, st);
     if (m->ownership != 2 || !m->view_block_begin) ensure_struct_hash(m, st);
