@@ -205,7 +205,8 @@ typedef struct {
 #define BMSP_MAC_STAGED 1  /* tc 4: K = 32 MFMA, operands staged through LDS per task (sparse task lists) */
 #define BMSP_MAC_DIRECT 2  /* tc 4: K = 32 MFMA, operand lines loaded per task straight into the MFMA lanes */
 #define BMSP_MAC_STRIP 3   /* tc 4: K = 32 MFMA, two block-rows of C per wave, A tiles register-resident, B tiles loaded once per strip */
-#define BMSP_MAC_ROWSPARSE 5 /* tc 5, fp32 operands of nearly empty tiles (row-merge strip mode): V15's fmaf chain over the products of STORED values only, accumulators per C value in LDS */
+#define BMSP_MAC_ROWSPARSE 5 /* V15 numerics (fp32 operands; fp16 operands under tc 5) on operands of nearly empty tiles (row-merge strip mode): the
+                             * reference's chain over the products of STORED values only, row-wise over CSR copies, accumulators per C value in LDS */
 #define BMSP_MAC_F32MFMA 4 /* tc 5, fp32, opt-in (BMSP_MAC_F32MFMA=1): V15's fmaf chain on v_mfma_f32_16x16x4_f32, operands from lane-ordered tile copies */
 
 /* sort modes = the reference's `segmented` argument (src/bmSparse_SPGEMM.cu:963-1016):
