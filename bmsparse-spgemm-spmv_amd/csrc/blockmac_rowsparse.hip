@@ -28,8 +28,10 @@
 namespace bmsp {
 namespace {
 
-constexpr int kRsHashBits = 9, kRsHash = 1 << kRsHashBits;
-constexpr uint32_t kRsRowCap = 256;   // C tiles per block-row (the strip kernels' limit: mac_strip_row_cap)
+// the table of a block-row's C columns: 2^HB slots.  HB = 9 for at most 256 tiles (strip mode's bound; 17.1 KB of LDS: nine workgroups per
+// CU -- a 385-entry offset array made it eight, FEM-like T_7 285 -> 324 us) or 10 for at most 768 (products that come with a task list,
+// cage-like block-rows of 400 - 600 tiles; 27 KB, five workgroups per CU)
+constexpr uint32_t rs_row_cap(int hb) { return hb == 9 ? 256u : 768u; }
 constexpr uint32_t kRsAcc = 2048;     // accumulators per window
 constexpr uint32_t kRsEmpty = 0xffffffffu;
 
@@ -50,17 +52,21 @@ typedef float f32x2s __attribute__((ext_vector_type(2)));
 // an entry {column, value bits} as a FLOAT vector: __builtin_bit_cast(float, v[1]) of an integer vector's element reads element 0 with this
 // compiler (ROCm 7.2) -- element 1 is read as the float it is, element 0 is cast to the column
 __device__ __forceinline__ f32x2s rs_entry(rsrc_t r, uint32_t byte_off) { return __builtin_bit_cast(f32x2s, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0)); }
+template <int HB>
 struct alignas(16) RsLds {
-    u32x4s slot[kRsHash];        // {block column of a C tile of the block-row (kRsEmpty = free), its first value relative to the block-row's
+    u32x4s slot[1 << HB];        // {block column of a C tile of the block-row (kRsEmpty = free), its first value relative to the block-row's
                                  // first, its bitmap (lo, hi)}: ONE 16-byte read per probe gives all a product needs
-    uint32_t co[kRsRowCap + 1];  // first value of every C tile relative to the block-row's first, in tile order (the windows' bounds)
+    uint32_t co[rs_row_cap(HB) + 1];  // first value of every C tile relative to the block-row's first, in tile order (the windows' bounds)
     float acc[kRsAcc];
-};  // 17 KB: nine one-wave workgroups per CU
+};  // HB = 9: 17.6 KB, nine one-wave workgroups per CU
 
-__device__ __forceinline__ uint32_t rs_hash(uint32_t j) { return (j * 0x9E3779B1u) >> (32 - kRsHashBits); }
+template <int HB>
+__device__ __forceinline__ uint32_t rs_hash(uint32_t j) { return (j * 0x9E3779B1u) >> (32 - HB); }
 
-// L = lanes per row of C: the wave's 64 / L lane groups take the block-row's eight rows 64 / L at a time (rows of different index never
-// meet in a C element), a group's L lanes = L entries of B's row k.  (The kernel is bound by its instruction count -- 1.4 M iterations of
+// L = lanes per row of C, a group's L lanes = L entries of B's row k.  A workgroup of L / 8 waves owns the block-row: its eight lane groups
+// take the eight rows at once (rows of different index never meet in a C element), table and accumulators are shared, built and stored
+// by all waves (one wave per block-row walked the rows 64 / L at a time: a cage-like block-row is 32 short iterations behind 30 us of
+// set-up and dependent loads, at five waves per CU).  (The kernel is bound by its instruction count -- 1.4 M iterations of
 // ~110 vector instructions on the FEM-like product, where a 16-byte table slot instead of four dependent LDS reads and requests three
 // entries ahead instead of one changed nothing (407 -> 410 us) -- so L follows B's average row length, the bitmap arithmetic is
 // 32-bit (the row is uniform per group), and an entry is one 8-byte buffer load.)
@@ -68,11 +74,14 @@ __device__ __forceinline__ uint32_t rs_hash(uint32_t j) { return (j * 0x9E3779B1
 // the fp32 add (:269-273, `__half * __half`); the entries hold the fp16 values widened to fp32 (exact), their fp32 product is exact (11 x
 // 11 bits), so one conversion to fp16 is that rounding.  No exponent condition there: an fp32 sum of fp16 values never underflows, and
 // +0 + -0 = +0, so a sum is never -0 and a left-out zero term never shows.
-template <int L, bool HALF>
-__global__ __launch_bounds__(64) void block_mac_rowsparse_kernel(RsArgs g)
+template <int L, bool HALF, int HB>
+__global__ __launch_bounds__(8 * L) void block_mac_rowsparse_kernel(RsArgs g)
 {
-    __shared__ RsLds S;
-    const int lane = (int)threadIdx.x;
+    constexpr uint32_t kRsHash = 1u << HB, kRsRowCap = rs_row_cap(HB);
+    constexpr uint32_t NT = 8u * L;  // threads: L / 8 waves
+    __shared__ RsLds<HB> S;
+    const int lane = lane_id();
+    const uint32_t tid = threadIdx.x;
     // XCD-aware order: the workgroups of one XCD take a contiguous eighth of the block-rows (neighbours read the same rows of B)
     uint32_t brow;
     {
@@ -83,23 +92,23 @@ __global__ __launch_bounds__(64) void block_mac_rowsparse_kernel(RsArgs g)
     const uint32_t c0 = g.c_rowptr[brow], m = g.c_rowptr[brow + 1] - c0;
     if (m == 0 || m > kRsRowCap) return;  // (the launcher admits no product with a longer block-row of C)
     // ---- C's block-row: column table (column, value offset, bitmap per slot), value offsets in tile order ----
-    for (uint32_t s = (uint32_t)lane; s < (uint32_t)kRsHash; s += 64) S.slot[s] = u32x4s{kRsEmpty, 0u, 0u, 0u};
-    __builtin_amdgcn_wave_barrier();
+    for (uint32_t s = tid; s < (uint32_t)kRsHash; s += NT) S.slot[s] = u32x4s{kRsEmpty, 0u, 0u, 0u};
+    __syncthreads();
     const uint64_t vbase = g.c_offs[c0];
-    for (uint32_t r = (uint32_t)lane; r < m; r += 64) {
+    for (uint32_t r = tid; r < m; r += NT) {
         const uint32_t j = key_col(g.c_keys[c0 + r]);
         const uint64_t bm = g.c_bmps[c0 + r];
         const uint32_t off = (uint32_t)(g.c_offs[c0 + r] - vbase);
-        uint32_t slot = rs_hash(j);
+        uint32_t slot = rs_hash<HB>(j);
         uint32_t *const words = (uint32_t *)S.slot;
         while (atomicCAS(&words[4u * slot], kRsEmpty, j) != kRsEmpty) slot = (slot + 1u) & (uint32_t)(kRsHash - 1);  // (the columns of a block-row are distinct)
         words[4u * slot + 1u] = off; words[4u * slot + 2u] = (uint32_t)bm; words[4u * slot + 3u] = (uint32_t)(bm >> 32);
         S.co[r] = off;
     }
-    if (lane == 0) S.co[m] = (uint32_t)(g.c_offs[c0 + m] - vbase);
-    __builtin_amdgcn_wave_barrier();
+    if (tid == 0) S.co[m] = (uint32_t)(g.c_offs[c0 + m] - vbase);
+    __syncthreads();
 
-    constexpr int GROUPS = 64 / L, PASSES = 8 / GROUPS;
+    constexpr int GROUPS = 64 / L;  // lane groups per wave; GROUPS * (L / 8) = 8 rows at once
     const int grp = lane / L, ll = lane % L, gbase = lane - ll;
     const rsrc_t ra = make_rsrc(g.a_ent, g.a_ent_bytes), rb = make_rsrc(g.b_ent, g.b_ent_bytes);
     for (uint32_t w0 = 0; w0 < m;) {
@@ -114,11 +123,10 @@ __global__ __launch_bounds__(64) void block_mac_rowsparse_kernel(RsArgs g)
             if (cnt < 64u) break;
         }
         const uint32_t nv = S.co[w1] - o0;
-        for (uint32_t e = (uint32_t)lane; e < nv; e += 64) S.acc[e] = 0.f;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-        for (int ps = 0; ps < PASSES; ps++) {
-            const uint32_t i = (uint32_t)(GROUPS * ps + grp);  // row inside the tiles: bits 8 i .. 8 i + 7 of a C bitmap, MSB first
+        for (uint32_t e = tid; e < nv; e += NT) S.acc[e] = 0.f;
+        __syncthreads();
+        {
+            const uint32_t i = (uint32_t)(GROUPS * wave_id() + grp);  // row inside the tiles: bits 8 i .. 8 i + 7 of a C bitmap, MSB first
             const uint32_t row = brow * 8u + i;
             const bool top = i < 4u;                   // the row's byte lies in the bitmap's high word
             const uint32_t sh0 = 24u - 8u * (i & 3u);  // ... at this shift
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(64) void block_mac_rowsparse_kernel(RsArgs g)
                 };
                 auto product = [&](uint32_t col, float b, float a) {
                     const uint32_t jb = col >> 3, j = col & 7u;
-                    uint32_t slot = rs_hash(jb);
+                    uint32_t slot = rs_hash<HB>(jb);
                     for (;;) {
                         const u32x4s sl = S.slot[slot];
                         if (sl[0] == jb) {
@@ -202,11 +210,11 @@ __global__ __launch_bounds__(64) void block_mac_rowsparse_kernel(RsArgs g)
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         // ---- the window's values leave in one run ----
         float *const dst = g.c_vals + vbase + o0;
-        for (uint32_t e = (uint32_t)lane; e < nv; e += 64) dst[e] = S.acc[e];
-        __builtin_amdgcn_wave_barrier();
+        for (uint32_t e = tid; e < nv; e += NT) dst[e] = S.acc[e];
+        __syncthreads();
         w0 = w1;
     }
 }
@@ -328,6 +336,14 @@ bool mac_rowsparse_applies(bmsp_matrix_s *A, bmsp_matrix_s *B, int tc_version, h
     return A->dtype != BMSP_F32 || A->f32_exp_min + B->f32_exp_min >= 128;
 }
 
+// every block-row of C within the larger table's capacity
+bool mac_rowsparse_fits_c(bmsp_matrix_s *C, hipStream_t st)
+{
+    if (C->block_num >= (1ll << 31) || C->block_num == 0) return false;
+    ensure_row_stats(C, st);
+    return (uint64_t)C->max_row_blocks <= rs_row_cap(10);
+}
+
 void launch_mac_rowsparse(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st)
 {
     ensure_csr32(A, st);
@@ -338,15 +354,27 @@ void launch_mac_rowsparse(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, 
     g.b_rowptr = B->csr_rowptr; g.b_ent = B->csr_ent; g.b_rows = (uint32_t)B->num_rows; g.b_ent_bytes = (uint32_t)((uint64_t)B->nnz * 8u);
     g.c_keys = C->keys; g.c_bmps = C->bmps; g.c_offs = C->offsets; g.c_rowptr = C->rowptr; g.c_vals = (float *)C->values;
     g.block_rows = (uint32_t)A->num_block_rows();
-    // lanes per row of C from B's average row length (a group's lanes = the entries of one row of B); BMSP_RS_LANES = 8 / 16 / 32 for A/B runs
+    // lanes per row of C = 8 x the waves per block-row.  Measured (T_7, us; FEM-like, rows of B of 26 / cage-like, 15.6): 8 lanes, one
+    // wave 292 / 625; 16 lanes, two waves 174 / 380; 32 lanes, four waves 134 / 277 -- the waves per block-row matter more than the lanes a
+    // short row of B leaves idle; only rows of B of a few entries take fewer.  BMSP_RS_LANES = 8 / 16 / 32 for A/B runs
     const uint64_t avg = B->num_rows ? (uint64_t)B->nnz / (uint64_t)B->num_rows : 0;
-    int lanes = avg <= 10 ? 8 : (avg <= 20 ? 16 : 32);
+    int lanes = avg <= 3 ? 8 : (avg <= 6 ? 16 : 32);
     if (const char *e = getenv("BMSP_RS_LANES")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32) lanes = v; }
-    const dim3 grid(g.block_rows), block(64);
+    const dim3 grid(g.block_rows), block(8u * (unsigned)lanes);
     const bool half = A->dtype == BMSP_F16;
-    if (lanes == 8) { if (half) hipLaunchKernelGGL((block_mac_rowsparse_kernel<8, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((block_mac_rowsparse_kernel<8, false>), grid, block, 0, st, g); }
-    else if (lanes == 16) { if (half) hipLaunchKernelGGL((block_mac_rowsparse_kernel<16, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((block_mac_rowsparse_kernel<16, false>), grid, block, 0, st, g); }
-    else { if (half) hipLaunchKernelGGL((block_mac_rowsparse_kernel<32, true>), grid, block, 0, st, g); else hipLaunchKernelGGL((block_mac_rowsparse_kernel<32, false>), grid, block, 0, st, g); }
+    ensure_row_stats(C, st);
+    const bool big = (uint64_t)C->max_row_blocks > rs_row_cap(9);  // (mac_rowsparse_fits_c has bounded it by rs_row_cap(10))
+#define BMSP_RS_LAUNCH(L_, H_, B_) hipLaunchKernelGGL((block_mac_rowsparse_kernel<L_, H_, B_>), grid, block, 0, st, g)
+#define BMSP_RS_PICK(L_) \
+    do { \
+        if (half) { if (big) BMSP_RS_LAUNCH(L_, true, 10); else BMSP_RS_LAUNCH(L_, true, 9); } \
+        else { if (big) BMSP_RS_LAUNCH(L_, false, 10); else BMSP_RS_LAUNCH(L_, false, 9); } \
+    } while (0)
+    if (lanes == 8) BMSP_RS_PICK(8);
+    else if (lanes == 16) BMSP_RS_PICK(16);
+    else BMSP_RS_PICK(32);
+#undef BMSP_RS_PICK
+#undef BMSP_RS_LAUNCH
     BMSP_CHECK_LAUNCH();
 }
 

@@ -156,6 +156,7 @@ bool mac_structure_numeric_ok(bmsp_matrix_s *A, bmsp_matrix_s *B, int tc_version
 void ensure_csr32(bmsp_matrix_s *m, hipStream_t st);
 bool mac_rowsparse_applies(bmsp_matrix_s *A, bmsp_matrix_s *B, int tc_version, hipStream_t st);
 void launch_mac_rowsparse(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, hipStream_t st);
+bool mac_rowsparse_fits_c(bmsp_matrix_s *C, hipStream_t st);  // every block-row of C within the row-sparse kernel's table (768 tiles)
 bool rowmerge_symbolic(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, uint32_t row_cap,
                        uint64_t *surviving, uint64_t *candidates, hipStream_t st);
 bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, const uint64_t *first_pos, uint64_t total, DevBuf<uint64_t> &tasks,

@@ -951,6 +951,12 @@ static void launch_block_mac(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *
         }
         BMSP_CHECK_LAUNCH();
         S->mac_kernel = tc_version;
+    } else if (A->dtype != BMSP_F64 && !getenv("BMSP_MAC_VALU_DENSE") && !getenv("BMSP_MAC_F32MFMA") && mac_rowsparse_applies(A, B, tc_version, st) &&
+               mac_rowsparse_fits_c(C, st)) {
+        // V15 numerics on operands of nearly empty tiles: the products of stored values only (blockmac_rowsparse.hip); the task list is not read
+        launch_mac_rowsparse(A, B, C, st);
+        S->mac_variant = BMSP_MAC_ROWSPARSE;
+        S->mac_kernel = 5;
     } else {
         if (A->dtype == BMSP_F32 && launch_mac_f32_mfma(tasks_sorted, n_tasks, task_begin, c_of_wave, A, B, C, st)) S->mac_variant = BMSP_MAC_F32MFMA;
         else if (A->dtype == BMSP_F32) launch_mac_valu<float>(tasks_sorted, task_begin, A, B, C, st);

@@ -687,6 +687,33 @@ def test_spgemm_rowsparse_block_mac(oracle, bmsp, monkeypatch, case, dtype, lane
     assert st["sort_path"] == 2 and (st["c_blocks"] == 0 or (st["mac_variant"] == 5 and st["mac_kernel"] == 5)), st
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_spgemm_rowsparse_after_task_list(oracle, bmsp, dtype):
+    """V15 numerics on operands of nearly empty tiles whose block-rows of C exceed strip mode's 256 tiles (here ~470 of them): the product
+    takes the row-merge task-list mode for C's structure, and the numeric stage is still the row-sparse kernel -- with its 1024-slot table
+    -- instead of the vector-ALU kernel on the task list.  Bit for bit the oracle's, fp32 and fp16 / tc_version 5."""
+    rng = np.random.default_rng(23)
+    n = 8 * 512
+    def coo(per_block_row, seed, full_rows):
+        # `per_block_row` tiles per block-row at random block columns; A's tiles hold one full row (all eight k of the tile: every tile of B's
+        # block-row survives the bitmap filter), B's tiles two values
+        r = np.random.default_rng(seed)
+        br = np.repeat(np.arange(512), per_block_row); bc = r.integers(0, 512, br.size)
+        key = np.unique(br.astype(np.int64) * 512 + bc)
+        br, bc = key // 512, key % 512
+        if full_rows:
+            rows = np.repeat(br * 8 + r.integers(0, 8, br.size), 8); cols = (np.repeat(bc * 8, 8) + np.tile(np.arange(8), br.size))
+        else:
+            rows = np.concatenate([br * 8 + r.integers(0, 4, br.size), br * 8 + 4 + r.integers(0, 4, br.size)])
+            cols = np.concatenate([bc * 8 + r.integers(0, 8, br.size), bc * 8 + r.integers(0, 8, br.size)])
+        return (n, n, rows, cols, np.round(r.standard_normal(rows.size) * 16) / 16 + 0.03125)
+    A, Bc = coo(20, 1, True), coo(25, 2, False)
+    st = check_spgemm(oracle, bmsp, A, Bc, dtype, 0, 5)
+    per_row = st["c_blocks"] / 512.0
+    assert 256 < per_row < 700, per_row
+    assert st["sort_path"] == 2 and st["mac_variant"] == 5 and st["mac_kernel"] == 5, st
+
+
 def test_mfma_f32_accumulation_order(bmsp):
     """v_mfma_f32_16x16x4_f32 accumulates its four k as the ascending fmaf chain (checked on the hardware against a host fmaf chain on
     random operands of mixed magnitude): the property the fp32 matrix-core block-MAC (BMSP_MAC_F32MFMA) rests on."""
@@ -871,7 +898,9 @@ def test_spgemm_rowmerge_path(oracle, bmsp, monkeypatch, case, dtype):
     new, _ = bmsp.spgemm(a, b, tc_version=tc)
     monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "0")
     monkeypatch.setenv("BMSP_MAC_STRIP", "1")
+    monkeypatch.setenv("BMSP_MAC_ROWSPARSE", "0")   # the pipeline's own numeric stage: the vector-ALU kernel on the sorted task list
     old, sto = bmsp.spgemm(a, b, tc_version=tc)
+    monkeypatch.delenv("BMSP_MAC_ROWSPARSE")
     assert sto["sort_path"] in (0, 1) and (dtype == 1 or sto["mac_variant"] == 0)
     for x, y in zip(old.host_arrays(), new.host_arrays()):
         np.testing.assert_array_equal(x, y)
