@@ -461,6 +461,192 @@ __global__ __launch_bounds__(kThreads) void rowmerge_build_kernel(TaskListArgs g
     if (lane == 0) { g.cnt[row] = m; g.surv[row] = ns; g.nnz[row] = nz; }
 }
 
+// ---- the build pass with a WORKGROUP per block-row (round 4) ---------------------------------------------------------------------------
+// One wave per block-row is a serial chain -- a step's record load, table insert, parked stores, one A tile after the other: ~90 us for
+// a cage-like block-row of 36 A tiles at 16 waves per CU, 372 us for the pass.  Here the four waves of a workgroup share the block-row:
+// wave w walks the w-th quarter of its A tiles (a contiguous range, in order) and parks its surviving pairs in the stretch of ITS
+// candidate pairs; the column table is shared (LDS atomics), the task counts are kept per wave and slot.  A task's place inside its C
+// tile -- ascending A tile, V15's summation order (:269-273) -- is then (tasks of the tile from earlier waves) + (the count the pair found
+// in its own wave's field on arrival): the waves' ranges ascend, inside a range the arrival order is the A-tile order, and the columns of
+// one step are distinct.  Cage-like product: the pass 372 -> 340 us (T_3 520 -> 490).  (A count pass + fill pass built on the same
+// ordering -- no parked pairs, the fill pass writing tasks and C tiles straight to their final places, no copy pass, no global atomic --
+// was written and measured: 247 + 192 us against 340 + 92; clearing 20 KB of tables and the ranking's barriers per block-row at five
+// workgroups per CU cost what the parked traffic costs.  Removed.)
+constexpr int kBwWaves = 4;
+struct alignas(16) BuildWgLds {
+    uint32_t hk[kTlHash];                    // block column; kEmpty = free
+    uint32_t tc[kBwWaves][kTlHash / 2];      // per wave: two 16-bit task counts per word; after the ranking: the tasks of the slot's tile from earlier waves
+    uint16_t list[kTlHash];                  // the tiles' task counts in rank order, then their exclusive scan
+    uint16_t rank_of[kTlHash];               // slot -> rank
+    ChunkLds ch[kBwWaves];                   // the walks' chunks; ch[0] after the walks: the ranking's bit words
+    uint16_t bp[32];
+    uint32_t n_cols, n_surv, abort_flag, jmin, jmax, nz;
+};  // 21 KB per workgroup: seven per CU, 28 waves
+
+template <int DEPTH>
+__global__ __launch_bounds__(64 * kBwWaves) void rowmerge_build_wg_kernel(TaskListArgs g)
+{
+    __shared__ BuildWgLds S;
+    const int w = wave_id(), lane = lane_id();
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t NT = 64 * kBwWaves;
+    const uint32_t row = xcd_order(blockIdx.x, gridDim.x);
+    if (row >= g.block_rows) return;
+    const uint32_t a0 = g.a_rowptr[row], a1 = g.a_rowptr[row + 1];
+    if (a0 == a1 || __builtin_nontemporal_load(g.overflow) != 0u) {
+        if (tid == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; g.nnz[row] = 0u; }
+        return;
+    }
+    const uint64_t off = g.first_pos[a0];
+    for (uint32_t s = tid; s < (uint32_t)kTlHash; s += NT) S.hk[s] = kEmpty;
+    for (uint32_t s = tid; s < (uint32_t)(kBwWaves * kTlHash / 2); s += NT) (&S.tc[0][0])[s] = 0u;
+    if (tid == 0) { S.n_cols = 0u; S.n_surv = 0u; S.abort_flag = a1 - a0 <= 65535u ? 0u : 1u; S.jmin = kEmpty; S.jmax = 0u; S.nz = 0u; }
+    __syncthreads();
+    // ---- the walks: wave w takes A tiles [aw0, aw1) ----
+    const uint32_t na = a1 - a0, q = (na + kBwWaves - 1) / kBwWaves;
+    const uint32_t aw0 = min(a0 + (uint32_t)w * q, a1), aw1 = min(aw0 + q, a1);
+    const uint64_t offw = aw0 < a1 ? g.first_pos[aw0] : off;
+    uint32_t ns = 0;  // this wave's surviving pairs so far (wave-uniform)
+    if (aw0 < aw1 && S.abort_flag == 0u) {
+        const bool done = walk_row<64, DEPTH>(g.w, S.ch[w], aw0, aw1, lane, [&](bool live, uint32_t a, uint32_t t, uint32_t j, uint64_t abm, uint32_t rows, uint64_t bbm) {
+            if (ns + 64u > 65535u || *(volatile uint32_t *)&S.abort_flag) return false;
+            const uint32_t ah = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(abm >> 32)), al = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)abm);
+            const uint32_t cols = tile_or_bytes(((uint64_t)ah << 32) | (uint64_t)al);
+            const bool keep = live && (cols & rows);  // multiplication_checker (:742-757)
+            const uint64_t bal = __ballot(keep);
+            bool fresh = false;
+            if (keep) {
+                const uint32_t slot = hash_insert<kTlBits>(S.hk, j, fresh);
+                const uint32_t old = atomicAdd(&S.tc[w][slot >> 1], 1u << (16u * (slot & 1u)));
+                const uint32_t k = ns + (uint32_t)__popcll(bal & lanemask_lt());
+                g.s_surv[offw + k] = ((uint64_t)slot << 48) | ((uint64_t)(a - a0) << 32) | (uint64_t)t;
+                g.s_prod[offw + k] = tile_product_scalar_a(ah, al, cols, (uint32_t)(bbm >> 32), (uint32_t)bbm);  // bmp_calculator (:787-810)
+                g.s_ord[offw + k] = (uint16_t)((old >> (16u * (slot & 1u))) & 0xffffu);
+            }
+            ns += (uint32_t)__popcll(bal);
+            const uint32_t nf = (uint32_t)__popcll(__ballot(fresh));
+            if (nf && lane == 0) {
+                if (atomicAdd(&S.n_cols, nf) + nf > kTlCap) S.abort_flag = 1u;  // the table would overflow: every wave leaves
+            }
+            return true;
+        });
+        if (!done && lane == 0) S.abort_flag = 1u;
+    }
+    if (lane == 0) atomicAdd(&S.n_surv, ns);
+    __syncthreads();
+    const uint32_t n = S.n_cols, ns_all = S.n_surv;
+    if (S.abort_flag != 0u || n > kTlCap || ns_all > 65535u) {  // (task offsets inside a block-row are kept in 16 bits)
+        if (tid == 0) { g.cnt[row] = 0u; g.surv[row] = 0u; g.nnz[row] = 0u; atomicOr(g.overflow, 1u); }
+        return;
+    }
+    // ---- rank of every column among the block-row's columns: counting sort by bitmap, a window of 8192 block columns at a time ----
+    constexpr uint32_t kWin = 8192, kWinWords = kWin / 64;
+    static_assert(sizeof(ChunkLds) == kWinWords * 8, "the bit words take a walk's chunk");
+    uint64_t *const bw = (uint64_t *)&S.ch[0];
+    {
+        uint32_t mn = kEmpty, mx = 0;
+        for (uint32_t s = tid; s < (uint32_t)kTlHash; s += NT) {
+            const uint32_t key = S.hk[s];
+            if (key != kEmpty) { mn = min(mn, key); mx = max(mx, key); }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, kWave));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, kWave));
+        }
+        if (lane == 0) { atomicMin(&S.jmin, mn); atomicMax(&S.jmax, mx); }
+    }
+    __syncthreads();
+    const uint32_t jmin = S.jmin, jmax = S.jmax;
+    uint32_t m = 0;  // columns ranked so far = columns below the current window
+    for (uint32_t lo = jmin; n; lo += kWin) {
+        for (uint32_t wd = tid; wd < kWinWords; wd += NT) bw[wd] = 0ull;
+        __syncthreads();
+        for (uint32_t s = tid; s < (uint32_t)kTlHash; s += NT) {
+            const uint32_t key = S.hk[s];
+            if (key != kEmpty && key - lo < kWin) atomicOr((unsigned long long *)&bw[(key - lo) >> 6], 1ull << ((key - lo) & 63u));
+        }
+        __syncthreads();
+        if (w == 0) {
+            uint32_t c = 0;
+            if (lane < (int)(kWinWords / 4))
+                c = (uint32_t)(__popcll(bw[4 * lane]) + __popcll(bw[4 * lane + 1]) + __popcll(bw[4 * lane + 2]) + __popcll(bw[4 * lane + 3]));
+            const uint32_t inc = wave_inclusive_sum(c);
+            if (lane < (int)(kWinWords / 4)) S.bp[lane] = (uint16_t)(inc - c);
+            if (lane == 63) S.nz = inc;  // (borrowed: the window's column count)
+        }
+        __syncthreads();
+        const uint32_t total = S.nz;
+        for (uint32_t s = tid; s < (uint32_t)kTlHash; s += NT) {
+            const uint32_t key = S.hk[s];
+            if (key != kEmpty && key - lo < kWin) {
+                const uint32_t wd = (key - lo) >> 6, bit = (key - lo) & 63u, w4 = wd & ~3u;
+                uint32_t rank = m + (uint32_t)S.bp[wd >> 2] + (uint32_t)__popcll(bw[wd] & ((1ull << bit) - 1ull));
+                if (wd > w4) rank += (uint32_t)__popcll(bw[w4]);
+                if (wd > w4 + 1) rank += (uint32_t)__popcll(bw[w4 + 1]);
+                if (wd > w4 + 2) rank += (uint32_t)__popcll(bw[w4 + 2]);
+                // the tile's task count (all waves) goes to its rank's place; each wave's field becomes the count of the waves before it
+                const uint32_t sh = 16u * (s & 1u);
+                uint32_t run = 0;
+#pragma unroll
+                for (int v = 0; v < kBwWaves; v++) {
+                    const uint32_t c = (S.tc[v][s >> 1] >> sh) & 0xffffu;
+                    atomicXor(&S.tc[v][s >> 1], (c ^ run) << sh);  // (xor: the neighbour slot shares the word)
+                    run += c;
+                }
+                S.list[rank] = (uint16_t)run;
+                S.rank_of[s] = (uint16_t)rank;
+                g.s_cols[off + rank] = key;
+            }
+        }
+        m += total;
+        __syncthreads();
+        if (jmax - lo < kWin) break;
+    }
+    // ---- exclusive scan of the task counts in rank order = first task of every C tile relative to the block-row's first ----
+    if (w == 0) {
+        uint32_t carry = 0;
+        for (uint32_t p0 = 0; p0 < m; p0 += 64) {
+            const uint32_t p = p0 + (uint32_t)lane;
+            const uint32_t v = p < m ? (uint32_t)S.list[p] : 0u;
+            const uint32_t inc = wave_inclusive_sum(v);
+            if (p < m) {
+                S.list[p] = (uint16_t)(carry + inc - v);
+                g.s_begin[off + p] = carry + inc - v;
+            }
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+    }
+    for (uint32_t p = tid; p < m; p += NT) g.s_bmps[off + p] = 0ull;
+    if (tid == 0) S.nz = 0u;
+    // the parked pairs and the zeroed bitmaps are written before other lanes of this workgroup read / OR into them (the workgroup's own CU:
+    // a wait for the stores; an agent-scope fence would write the XCD's L2 back)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    // ---- the parked pairs to their places, their products into the tiles' bitmaps: every wave its own ----
+    for (uint32_t k0 = 0; k0 < ns; k0 += 64) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        if (k < ns) {
+            const uint64_t e = g.s_surv[offw + k], pr = g.s_prod[offw + k];
+            const uint32_t ord = (uint32_t)g.s_ord[offw + k];
+            const uint32_t slot = (uint32_t)(e >> 48);
+            const uint32_t rank = (uint32_t)S.rank_of[slot];
+            const uint32_t before = (S.tc[w][slot >> 1] >> (16u * (slot & 1u))) & 0xffffu;
+            g.s_tasks[off + (uint32_t)S.list[rank] + before + ord] = ((uint64_t)(a0 + (uint32_t)((e >> 32) & 0xffffu)) << 32) | (e & 0xffffffffull);
+            atomicOr(&g.s_bmps[off + rank], (unsigned long long)pr);
+        }
+    }
+    // values of the block-row (bits of its finished bitmaps: read past the L1, which may still hold the zeroed lines)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    uint32_t nz = 0;
+    for (uint32_t p = tid; p < m; p += NT) nz += (uint32_t)__popcll(__hip_atomic_load(g.s_bmps + off + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    nz = wave_sum(nz);
+    if (lane == 0) atomicAdd(&S.nz, nz);
+    __syncthreads();
+    if (tid == 0) { g.cnt[row] = m; g.surv[row] = ns_all; g.nnz[row] = S.nz; }
+}
+
 // stretches -> C's own arrays and the task list: one wave per block-row
 __global__ __launch_bounds__(kThreads) void rowmerge_copy_kernel(TaskListArgs g)
 {
@@ -736,8 +922,13 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
     g.s_surv = s_surv.p; g.s_prod = s_prod.p; g.s_ord = s_ord.p; g.s_tasks = s_tasks.p; g.s_cols = s_cols.p; g.s_begin = s_begin.p;
     g.s_bmps = (unsigned long long *)s_bmps.p;
     const dim3 grid((uint32_t)((rows + 3) / 4));
-    if (getenv("BMSP_RM_DEPTH1")) hipLaunchKernelGGL(rowmerge_build_kernel<1>, grid, dim3(kThreads), 0, st, g);  // experiment switch
-    else hipLaunchKernelGGL(rowmerge_build_kernel<2>, grid, dim3(kThreads), 0, st, g);
+    // BMSP_RM_BUILD_WAVE=1: one wave per block-row (the form before round 4's workgroup per block-row; A/B runs and tests)
+    if (getenv("BMSP_RM_BUILD_WAVE")) {
+        if (getenv("BMSP_RM_DEPTH1")) hipLaunchKernelGGL(rowmerge_build_kernel<1>, grid, dim3(kThreads), 0, st, g);  // experiment switch
+        else hipLaunchKernelGGL(rowmerge_build_kernel<2>, grid, dim3(kThreads), 0, st, g);
+    } else {
+        hipLaunchKernelGGL(rowmerge_build_wg_kernel<2>, dim3((uint32_t)rows), dim3(64 * kBwWaves), 0, st, g);
+    }
     BMSP_CHECK_LAUNCH();
     uint32_t *c_rowptr = (uint32_t *)pool_alloc(sizeof(uint32_t) * (size_t)(rows + 1));
     HostScalar<uint32_t> c_size_h, n_tasks_h;

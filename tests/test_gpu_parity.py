@@ -687,6 +687,21 @@ def test_spgemm_rowsparse_block_mac(oracle, bmsp, monkeypatch, case, dtype, lane
     assert st["sort_path"] == 2 and (st["c_blocks"] == 0 or (st["mac_variant"] == 5 and st["mac_kernel"] == 5)), st
 
 
+def test_spgemm_task_list_build_one_wave_form(oracle, bmsp, monkeypatch):
+    """BMSP_RM_BUILD_WAVE=1: the row-merge build pass with one wave per block-row (the form before round 4's workgroup per block-row, kept
+    for A/B runs): same C, same task order -- the fp32 V15 values, which depend on it, are the oracle's bit for bit (the vector-ALU
+    kernel reads the task list: BMSP_MAC_ROWSPARSE=0)."""
+    from pybmsp import gen
+    n, _, r, c, v = gen.cage_like(40000, per_row=9.0)
+    A = (n, n, r, c, np.round(v * 64) / 64)
+    monkeypatch.setenv("BMSP_MAC_ROWSPARSE", "0")
+    monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "2")   # task-list mode only
+    st_wg = check_spgemm(oracle, bmsp, A, A, 0, 0, 5)
+    monkeypatch.setenv("BMSP_RM_BUILD_WAVE", "1")
+    st_wave = check_spgemm(oracle, bmsp, A, A, 0, 0, 5)
+    assert st_wg["sort_path"] == 2 and st_wave["sort_path"] == 2 and st_wg["mac_variant"] == 0 and st_wave["mac_variant"] == 0, (st_wg, st_wave)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_spgemm_rowsparse_after_task_list(oracle, bmsp, dtype):
     """V15 numerics on operands of nearly empty tiles whose block-rows of C exceed strip mode's 256 tiles (here ~470 of them): the product
