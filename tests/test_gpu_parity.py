@@ -578,7 +578,7 @@ def test_mfma32_block_mac_paths(oracle, bmsp, monkeypatch, case, b_dense, quota)
 
 @pytest.mark.parametrize("long_sort", ["merge", "radix"])
 @pytest.mark.parametrize("wide", [False, True])
-@pytest.mark.parametrize("case", ["two_pieces", "three_pieces", "rmat_hubs", "wide_cols"])
+@pytest.mark.parametrize("case", ["two_pieces", "three_pieces", "rmat_hubs", "wide_cols", "huge_cols"])
 def test_spgemm_long_segments_merge(oracle, bmsp, monkeypatch, case, wide, long_sort):
     """T_5, segmented path, block-rows whose task segment exceeds what a wave sorts in registers (4096 words, 2048 with 64-bit sort
     words).  `merge`: the segment is cut into pieces, the pieces are sorted like ordinary segments and merged by merge-path passes (one
@@ -594,12 +594,13 @@ def test_spgemm_long_segments_merge(oracle, bmsp, monkeypatch, case, wide, long_
     if case == "rmat_hubs":
         n, _, r, c, v = gen.rmat(12, 8)
         A = Bc = (n, n, r, c, v)
-    elif case == "wide_cols":
+    elif case in ("wide_cols", "huge_cols"):
         # block-rows 0 and 1 of A full over 300 block columns (6000 tasks each), block-rows 2 .. 5 short (one, two, 40 and 300 tiles);
         # every block-row of B: 20 one-value tiles, 12 of them at random block columns of 36 000, 8 at columns shared by all rows
         # (C tiles with 300 tasks whose order the sort must keep)
+        # (huge_cols: 5 000 000 block columns = 23 column bits: FOUR counting passes of 6 bits, sort words of 64 bits whatever the switch)
         rng = np.random.default_rng(17)
-        nk, nbc = 8 * 300, 36000
+        nk, nbc = 8 * 300, (36000 if case == "wide_cols" else 5000000)
         r = np.repeat(np.arange(16), nk); c = np.tile(np.arange(nk), 16)
         extra_r = np.concatenate([[16], [24, 24], np.full(40, 32), np.full(300, 40)])
         extra_c = np.concatenate([[8 * 7], [8 * 3, 8 * 250], 8 * np.arange(40) * 7, 8 * np.arange(300)])
