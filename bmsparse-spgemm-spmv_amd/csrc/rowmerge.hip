@@ -647,23 +647,26 @@ __global__ __launch_bounds__(64 * kBwWaves) void rowmerge_build_wg_kernel(TaskLi
     if (tid == 0) { g.cnt[row] = m; g.surv[row] = ns_all; g.nnz[row] = S.nz; }
 }
 
-// stretches -> C's own arrays and the task list: one wave per block-row
+// stretches -> C's own arrays and the task list: one wave per block-row (WG = false) or, with the workgroup build pass, a workgroup of
+// four waves per block-row (the tiles' words and the tasks spread over 256 lanes, the value offsets by the first wave)
+template <bool WG>
 __global__ __launch_bounds__(kThreads) void rowmerge_copy_kernel(TaskListArgs g)
 {
     const int lane = lane_id();
-    const uint32_t row = xcd_order(blockIdx.x, gridDim.x) * 4 + (uint32_t)wave_id();
+    const uint32_t row = WG ? xcd_order(blockIdx.x, gridDim.x) : xcd_order(blockIdx.x, gridDim.x) * 4 + (uint32_t)wave_id();
     if (row >= g.block_rows) return;
     const uint32_t c0 = g.c_rowptr[row], m = g.c_rowptr[row + 1] - c0;
     if (m == 0) return;
     const uint32_t t0 = g.row_task0[row], ns = g.row_task0[row + 1] - t0;
     const uint64_t off = g.first_pos[g.a_rowptr[row]];
-    for (uint32_t r = (uint32_t)lane; r < m; r += 64) {
+    const uint32_t tid = WG ? threadIdx.x : (uint32_t)lane, nt = WG ? (uint32_t)kThreads : 64u;
+    for (uint32_t r = tid; r < m; r += nt) {
         g.c_keys[c0 + r] = key_make(row, g.s_cols[off + r]);
         g.c_bmps[c0 + r] = (uint64_t)g.s_bmps[off + r];
         g.task_begin[c0 + r] = t0 + g.s_begin[off + r];
     }
-    for (uint32_t k = (uint32_t)lane; k < ns; k += 64) g.tasks[t0 + k] = g.s_tasks[off + k];
-    row_value_offsets((const uint64_t *)g.s_bmps + off, m, g.row_val0[row], g.c_offs + c0, lane);
+    for (uint32_t k = tid; k < ns; k += nt) g.tasks[t0 + k] = g.s_tasks[off + k];
+    if (!WG || wave_id() == 0) row_value_offsets((const uint64_t *)g.s_bmps + off, m, g.row_val0[row], g.c_offs + c0, lane);
 }
 
 // C tile of task 64 w (what the task-list block-MAC kernels index per 64 tasks)
@@ -975,7 +978,8 @@ bool rowmerge_tasklist(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s *C, con
         g.c_rowptr = c_rowptr; g.row_task0 = row_task0.p;
         g.row_val0 = row_val0.p;
         g.c_keys = C->keys; g.c_bmps = C->bmps; g.c_offs = C->offsets; g.task_begin = task_begin.p; g.tasks = tasks.p;
-        hipLaunchKernelGGL(rowmerge_copy_kernel, grid, dim3(kThreads), 0, st, g);
+        if (getenv("BMSP_RM_BUILD_WAVE")) hipLaunchKernelGGL(rowmerge_copy_kernel<false>, grid, dim3(kThreads), 0, st, g);
+        else hipLaunchKernelGGL(rowmerge_copy_kernel<true>, dim3((uint32_t)rows), dim3(kThreads), 0, st, g);
         BMSP_CHECK_LAUNCH();
         device_for_each(COfWave{task_begin.p, c_size, c_of_wave.p}, ((uint64_t)n_tasks + 63) / 64, st);
     }
