@@ -500,7 +500,7 @@ def stage_bytes(st, sort_bits):
     """compulsory bytes of the symbolic stages for THIS library's layouts (DESIGN.md section 4 states them next to SURVEY 8(d)'s figures
     for the reference's 16-byte tasks): per candidate pair / surviving task / C block.  Keyed by the stage the time is charged to."""
     cand, surv, cb = st["task_list_size"], st["surviving_tasks"], st["c_blocks"]
-    if st["sort_path"] == 2 and st.get("mac_variant") in (3, 5):
+    if st["sort_path"] == 2 and st.get("sort_long") == 1:
         # row-merge, strip mode (rowmerge_symbolic_kernel + emit): key + bitmap of B's tile per candidate pair; C's column + bitmap to scratch
         # (12 B), read back by the emit pass, C's key + bitmap + offset written (24 B).  T_3 holds all of it (T_9 is an allocation)
         return {"T_3": 16 * cand + 48 * cb}
@@ -658,7 +658,7 @@ def bench_spgemm(B, gen, np, args):
                     "stage_us": {k: round(best["t_us"][i], 1) for k, i in stage_idx},
                     "stage_GBs": stage_gbs, "stage_frac_of_hbm_peak": stage_frac,
                     "sort_path": {0: "global radix", 1: "segmented" + {0: "", 1: " (long block-rows: pieces + merge passes)",
-                                                                       2: " (long block-rows: counting passes on the column bits)"}[best.get("sort_long", 0)], 2: "none (row-merge: C's structure formed per block-row in LDS)",
+                                                                       2: " (long block-rows: counting passes on the column bits)"}[best.get("sort_long", 0)], 2: "none (row-merge, %s: C's structure formed per block-row in LDS)" % {1: "strip mode", 2: "task-list mode"}.get(best.get("sort_long", 0), "?"),
                                   3: "none (column windows: C's structure formed per block-row and window of block columns in dense LDS tables)"}[best["sort_path"]],
                     "roofline": roof})
         del A, At

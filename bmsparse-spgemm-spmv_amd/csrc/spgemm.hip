@@ -1104,6 +1104,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
             S->surviving_tasks = (int64_t)surv;
             S->bmp_reduction = (int64_t)(total - surv);
             S->sort_path = BMSP_SORT_PATH_ROWMERGE;
+            S->sort_long = BMSP_ROWMERGE_STRIP;
             finish_structure();
             tm.mark(9);
             if (C->block_num && !structure_only) {
@@ -1171,6 +1172,7 @@ void spgemm(bmsp_matrix_s *A, bmsp_matrix_s *B, bmsp_matrix_s **Cout, int mode, 
                 S->surviving_tasks = (int64_t)n_tasks;
                 S->bmp_reduction = (int64_t)(total - n_tasks);
                 S->sort_path = got == 2 ? BMSP_SORT_PATH_ROWMERGE : BMSP_SORT_PATH_ROWWINDOW;
+                if (got == 2) S->sort_long = BMSP_ROWMERGE_TASKLIST;
                 finish_structure();
                 tm.mark(9);
             } else {

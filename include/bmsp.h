@@ -193,11 +193,14 @@ typedef struct {
                               * block-row by block-row in LDS (BMSP_SORT_PATH_ROWMERGE; T_3 then holds the whole symbolic pass) */
     int mac_kernel;          /* which block-MAC kernel ran (see tc_version) */
     int mac_variant;         /* which implementation of it: BMSP_MAC_* below */
-    int sort_long;           /* sort_path 1 only: how block-rows of more tasks than one wave sorts in registers were ordered -- 0 = there were
-                              * none, 1 = pieces + merge passes, 2 = stable counting passes on the column bits (BMSP_SORT_LONG_*) */
+    int sort_long;           /* detail of sort_path.  sort_path 1: how block-rows of more tasks than one wave sorts in registers were ordered -- 0 =
+                              * there were none, 1 = pieces + merge passes, 2 = stable counting passes on the column bits (BMSP_SORT_LONG_*).
+                              * sort_path 2 (row-merge): 1 = strip mode (C's structure only, no task list), 2 = task-list mode (BMSP_ROWMERGE_*) */
 } bmsp_spgemm_stats;
 /* implementations behind one tc_version (the launcher picks by the product's shape; all give the tc_version's numerics) */
 #define BMSP_SORT_PATH_ROWMERGE 2
+#define BMSP_ROWMERGE_STRIP 1
+#define BMSP_ROWMERGE_TASKLIST 2
 #define BMSP_SORT_LONG_MERGE 1
 #define BMSP_SORT_LONG_RADIX 2
 #define BMSP_SORT_PATH_ROWWINDOW 3 /* none either: block-rows of C formed window by window of block columns in dense LDS tables (operands with hub block-rows) */
