@@ -11,14 +11,14 @@
 // only after a product has underflowed: the launcher takes this kernel only for operands whose exponent ranges keep every product of
 // stored values a normal number (the precondition of the fp32 matrix-core kernel, mac_strip_operands_ok), and for finite values (0 x inf).
 //
-// One wave per block-row of C; C's structure is given (T_3 ... T_9 have fixed it).  Accumulators: one float per stored value of the
-// block-row, in LDS (a window of C tiles of at most kRsAcc values at a time; a block-row that holds more is walked once per window);
-// C's block columns of the block-row in an LDS hash table.  The two halves of the wave take the block-row's eight rows in turn (rows of
-// different index never meet in a C element); a half walks its row of A entry by entry (32 entries and the bounds of their rows of B
-// fetched together, handed round by shuffles), 32 lanes = 32 entries of B's row k: column -> C tile (hash) -> slot (rank in C's
-// bitmap) -> one LDS read-modify-write.  Inside an iteration the 32 products of a half go to 32 different columns of one row: no
-// conflicts, no atomics.  Operands: row-major CSR copies (row pointer, column, value) derived once per matrix, like the dense copies
-// the matrix-core kernels read.
+// One workgroup (L / 8 waves) per block-row of C; C's structure is given (T_3 ... T_9 have fixed it).  Accumulators: one float per stored
+// value of the block-row, in LDS (a window of C tiles of at most kRsAcc values at a time; a block-row that holds more is walked once per
+// window); C's block columns of the block-row in an LDS hash table.  The workgroup's eight groups of L lanes take the block-row's eight
+// rows at once (rows of different index never meet in a C element); a group walks its row of A entry by entry (L entries and the bounds
+// of their rows of B fetched together, handed round by shuffles), its L lanes = L entries of B's row k: column -> C tile (hash) -> slot
+// (rank in C's bitmap) -> one LDS read-modify-write.  Inside an iteration the products of a group go to different columns of one row:
+// no conflicts, no atomics.  Operands: row-major CSR copies (row pointer, {column, value} entries) derived once per matrix, like the
+// dense copies the matrix-core kernels read.
 // (Two forms that walked the tiles themselves -- one A tile per step, lane = a tile of B's block-row k, the A tile's values in a scalar
 // loop -- measured 1171 and 1084 us on the FEM-like product, the second with B's values parked in LDS: 96 products per step spread over
 // eleven serialized read-modify-write iterations at one lane in seven.)
