@@ -213,7 +213,8 @@ __global__ __launch_bounds__(kThreads) void rowmerge_symbolic_kernel(RowMergeArg
         bool fresh = false;
         if (keep) {
             // bmp_calculator (:787-810) in its byte-permute form on the row-major B tile (88 instead of ~240 vector instructions: this pass was
-            // 85 % VALU-bound on the FEM-like product); two full tiles: a full one
+            // 85 % VALU-bound on the FEM-like product); two full tiles: a full one.  (One A tile per step with the A side in scalar registers,
+            // as in the build pass, measured SLOWER here: FEM-like T_3 202 -> 218 us at 55 of 64 lanes, the dense band 316 -> 603 us.)
             const uint64_t prod = (abm & bbm) == ~0ull ? ~0ull : tile_product_rm(abm, bbm);
             const uint32_t slot = hash_insert(S.hk, j, fresh);
             atomicOr((unsigned long long *)&S.hb[slot], (unsigned long long)prod);
