@@ -168,6 +168,22 @@ __device__ __forceinline__ uint32_t hash_insert(uint32_t *hk, uint32_t j, bool &
         slot = (slot + 1u) & ((1u << BITS) - 1u);
     }
 }
+// the same for a table that SEVERAL waves fill at once: the waves look at the column count once per step, so up to (waves x 64) inserts
+// are under way when the cap is passed and the table can fill up -- an unbounded probe would then never end (found by a hang of
+// test_spgemm_synthetic[0-5-wide]: 896 + 4 x 64 > 1024).  full = every slot was probed: the block-row has more columns than the table
+// holds, the caller voids the pass
+template <int BITS>
+__device__ __forceinline__ uint32_t hash_insert_bounded(uint32_t *hk, uint32_t j, bool &fresh, bool &full)
+{
+    uint32_t slot = (j * 0x9E3779B1u) >> (32 - BITS);
+    for (uint32_t probes = 0; probes < (1u << BITS); probes++) {
+        const uint32_t old = atomicCAS(&hk[slot], kEmpty, j);
+        if (old == kEmpty || old == j) { fresh = old == kEmpty; full = false; return slot; }
+        slot = (slot + 1u) & ((1u << BITS) - 1u);
+    }
+    fresh = false; full = true;
+    return 0u;
+}
 __device__ __forceinline__ uint32_t xcd_order(uint32_t b, uint32_t G)
 {  // the workgroups of one XCD take a contiguous eighth of the block-rows (neighbouring rows read the same block-rows of B)
     const uint32_t q = G / 8, rm = G % 8, x = b % 8;
@@ -515,14 +531,20 @@ __global__ __launch_bounds__(64 * kBwWaves) void rowmerge_build_wg_kernel(TaskLi
             const uint32_t cols = tile_or_bytes(((uint64_t)ah << 32) | (uint64_t)al);
             const bool keep = live && (cols & rows);  // multiplication_checker (:742-757)
             const uint64_t bal = __ballot(keep);
-            bool fresh = false;
+            bool fresh = false, full = false;
             if (keep) {
-                const uint32_t slot = hash_insert<kTlBits>(S.hk, j, fresh);
-                const uint32_t old = atomicAdd(&S.tc[w][slot >> 1], 1u << (16u * (slot & 1u)));
-                const uint32_t k = ns + (uint32_t)__popcll(bal & lanemask_lt());
-                g.s_surv[offw + k] = ((uint64_t)slot << 48) | ((uint64_t)(a - a0) << 32) | (uint64_t)t;
-                g.s_prod[offw + k] = tile_product_scalar_a(ah, al, cols, (uint32_t)(bbm >> 32), (uint32_t)bbm);  // bmp_calculator (:787-810)
-                g.s_ord[offw + k] = (uint16_t)((old >> (16u * (slot & 1u))) & 0xffffu);
+                const uint32_t slot = hash_insert_bounded<kTlBits>(S.hk, j, fresh, full);
+                if (!full) {
+                    const uint32_t old = atomicAdd(&S.tc[w][slot >> 1], 1u << (16u * (slot & 1u)));
+                    const uint32_t k = ns + (uint32_t)__popcll(bal & lanemask_lt());
+                    g.s_surv[offw + k] = ((uint64_t)slot << 48) | ((uint64_t)(a - a0) << 32) | (uint64_t)t;
+                    g.s_prod[offw + k] = tile_product_scalar_a(ah, al, cols, (uint32_t)(bbm >> 32), (uint32_t)bbm);  // bmp_calculator (:787-810)
+                    g.s_ord[offw + k] = (uint16_t)((old >> (16u * (slot & 1u))) & 0xffffu);
+                }
+            }
+            if (__any(full)) {  // (the pass is void: the table is full)
+                if (lane == 0) S.abort_flag = 1u;
+                return false;
             }
             ns += (uint32_t)__popcll(bal);
             const uint32_t nf = (uint32_t)__popcll(__ballot(fresh));

@@ -688,6 +688,27 @@ def test_spgemm_rowsparse_block_mac(oracle, bmsp, monkeypatch, case, dtype, lane
     assert st["sort_path"] == 2 and (st["c_blocks"] == 0 or (st["mac_variant"] == 5 and st["mac_kernel"] == 5)), st
 
 
+def test_spgemm_task_list_table_overflow(oracle, bmsp, monkeypatch):
+    """A block-row of C with far more columns than the build pass's table holds (2400 against 1024 slots), every wave of the workgroup
+    inserting from its first step on: the pass must give up -- a probe of a FULL table that never ended hung test_spgemm_synthetic[0-5-wide]
+    once the four waves' inserts happened to pass the cap together -- and the product must come out of the next path, bit for bit the
+    oracle's.  Several products in a row: the overflow is a matter of timing."""
+    nb = 8
+    ra = np.repeat(np.arange(8), 8 * nb); ca = np.tile(np.arange(8 * nb), 8)
+    A = (8, 8 * nb, ra, ca, 1.0 + (ra * 3 + ca) % 5)
+    rb, cb = [], []
+    for k in range(nb):                      # B's block-row k: 300 tiles at block columns of its own
+        cols = 8 * (300 * k + np.arange(300)) + (np.arange(300) % 8)
+        for kk in range(8):
+            rb.append(np.full(300, 8 * k + kk)); cb.append(cols)
+    rb = np.concatenate(rb); cb = np.concatenate(cb)
+    Bc = (8 * nb, 8 * 300 * nb, rb, cb, 1.0 + (rb + cb) % 3)
+    monkeypatch.setenv("BMSP_SPGEMM_ROWMERGE", "2")   # no strip mode: the task-list build pass is the first thing tried
+    for _ in range(4):
+        st = check_spgemm(oracle, bmsp, A, Bc, 0, 0, 5)
+        assert st["c_blocks"] == 300 * nb, st
+
+
 def test_spgemm_task_list_build_one_wave_form(oracle, bmsp, monkeypatch):
     """BMSP_RM_BUILD_WAVE=1: the row-merge build pass with one wave per block-row (the form before round 4's workgroup per block-row, kept
     for A/B runs): same C, same task order -- the fp32 V15 values, which depend on it, are the oracle's bit for bit (the vector-ALU
